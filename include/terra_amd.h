@@ -1,0 +1,160 @@
+/*
+ * terra_amd.h -- C-ABI of libterra_amd.so beyond the drop-in Terra.h surface.
+ *
+ * Plain pointers and sizes only; no C++ or framework types cross this boundary.
+ * Each entry point names the reference interface it replaces or serves
+ * (paths relative to the reference tree). INTEGRATION.md shows the binding a
+ * maintainer of the reference adds on their side.
+ *
+ * Conventions: functions returning int return 0 on success and a negative
+ * TerraAmdStatus on failure; the message is kept per thread and read with
+ * terra_amd_last_error(). Device pointers are raw HIP device addresses
+ * (e.g. hipMalloc() results or a tensor's data pointer); `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream).
+ */
+#ifndef TERRA_AMD_H
+#define TERRA_AMD_H
+
+#include "Terra.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    kTerraAmdOk               = 0,
+    kTerraAmdErrNoDevice      = -1,  /* no gfx950 device / HIP runtime failure */
+    kTerraAmdErrNotCommitted  = -2,  /* terra_scene_commit() has not run since the last change */
+    kTerraAmdErrUnsupported   = -3,  /* material/attribute uses host function pointers the device cannot run */
+    kTerraAmdErrBadArgument   = -4,
+    kTerraAmdErrLaunch        = -5
+} TerraAmdStatus;
+
+/* Last error recorded on the calling thread ("" if none). terra_render() is
+   void in the reference API (include/Terra.h:229), so this is its side channel. */
+const char* terra_amd_last_error ( void );
+void        terra_amd_clear_error ( void );
+
+/* Device selection for subsequent commits/renders issued by this thread's
+   scenes. One process drives one GPU in the multi-GPU layout. */
+int  terra_amd_device_count ( void );
+int  terra_amd_set_device ( int device );
+int  terra_amd_get_device ( void );
+
+/* Frame seed F of the per-pixel random streams (DESIGN.md "Randomness"):
+   replaces the reference's time(NULL)^&exit seed (src/Terra.c:679) and libc
+   rand() (src/Terra.c:115). Default 0x5EED0001. */
+void     terra_amd_set_frame_seed ( HTerraScene scene, uint64_t seed );
+uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
+
+/* Work counters of the device path, summed over all launches since the last
+   reset. They define the algorithmic bytes of the roofline:
+   bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels. */
+typedef struct {
+    uint64_t rays;          /* terra_scene_raycast equivalents (src/Terra.c:1623) */
+    uint64_t nodes;         /* BVH nodes popped (src/TerraBVH.c:267) */
+    uint64_t box_tests;     /* slab tests (src/Terra.c:851) */
+    uint64_t tri_tests;     /* watertight queries (src/TerraGeometry.c:159) */
+    uint64_t hits;          /* rays that hit: one terra_surface_init each (src/Terra.c:1726) */
+    uint64_t samples;       /* camera samples traced */
+    uint64_t rand_calls;    /* stream-B draws == the reference's rand() calls */
+    uint64_t attr_fetches;  /* (attributes_count + 1) summed over hits */
+    uint64_t pixels;        /* pixels written */
+    uint64_t launches;      /* render kernel launches */
+} TerraAmdStats;
+int terra_amd_get_stats ( HTerraScene scene, TerraAmdStats* out );
+int terra_amd_reset_stats ( HTerraScene scene );
+
+/* Flattened-scene facts after commit (for tests and the roofline model). */
+typedef struct {
+    uint32_t triangles, nodes, objects, lights;
+    uint32_t lights_triangles_count;
+    int32_t  max_stack;      /* traversal stack entries a ray can need */
+    uint64_t device_bytes;   /* HBM bytes held by the scene replica */
+} TerraAmdSceneInfo;
+int terra_amd_scene_info ( HTerraScene scene, TerraAmdSceneInfo* out );
+/* Copies the host BVH (reference node layout, src/TerraBVH.h:13-17, 64 B/node)
+   into `out` (capacity in nodes); returns the node count or a negative status. */
+int terra_amd_scene_bvh_nodes ( HTerraScene scene, void* out, int capacity );
+
+/* terra_render() (include/Terra.h:229, src/Terra.c:512-635) on a framebuffer
+   that already lives in HBM: d_pixels = float[3]*fb_width*fb_height,
+   d_results = {float acc[3]; int samples}*fb_width*fb_height, both row-major
+   like TerraFramebuffer. Asynchronous on `stream`; nothing is copied to the
+   host. d_rand_calls (optional, uint32 per pixel, same indexing) receives the
+   number of stream-B draws of this call per pixel. */
+int terra_amd_render_device ( const TerraCamera* camera, HTerraScene scene,
+                              void* d_pixels, void* d_results, size_t fb_width, size_t fb_height,
+                              size_t x, size_t y, size_t width, size_t height,
+                              void* d_rand_calls, void* stream );
+
+/* Tile-sharded form for one-process-per-GPU rendering (the reference shards
+   the same way over CPU threads: satellite/src/Renderer.cpp:316-350): the
+   rectangle is cut into tile_size x tile_size tiles numbered row-major and this
+   call renders the tiles t with t % world == rank. */
+int terra_amd_render_device_sharded ( const TerraCamera* camera, HTerraScene scene,
+                                      void* d_pixels, void* d_results, size_t fb_width, size_t fb_height,
+                                      size_t x, size_t y, size_t width, size_t height,
+                                      size_t tile_size, int rank, int world,
+                                      void* d_rand_calls, void* stream );
+
+/* Gather support for the sharded form: copy this rank's tiles of (pixels,
+   results) into / out of a packed buffer of tiles_of_rank * tile_size^2 * 28
+   bytes (12 B pixel + 16 B result per pixel, tile-major, rows inside a tile
+   contiguous). The packed buffers of all ranks are what the single RCCL gather
+   moves. Both return the number of tiles handled or a negative status. */
+int    terra_amd_shard_tile_count ( size_t width, size_t height, size_t tile_size, int rank, int world );
+size_t terra_amd_shard_packed_bytes ( size_t width, size_t height, size_t tile_size, int world );
+int terra_amd_pack_tiles ( const void* d_pixels, const void* d_results, size_t fb_width, size_t fb_height,
+                           size_t x, size_t y, size_t width, size_t height, size_t tile_size, int rank, int world,
+                           void* d_packed, void* stream );
+int terra_amd_unpack_tiles ( void* d_pixels, void* d_results, size_t fb_width, size_t fb_height,
+                             size_t x, size_t y, size_t width, size_t height, size_t tile_size, int rank, int world,
+                             const void* d_packed, void* stream );
+
+/* Blocks until all work this library queued on `stream` has finished. */
+int terra_amd_synchronize ( void* stream );
+
+/* Times `launches` back-to-back terra_amd_render_device() calls with HIP events
+   recorded on `stream` and returns the average kernel milliseconds in *ms_avg. */
+int terra_amd_time_render_device ( const TerraCamera* camera, HTerraScene scene,
+                                   void* d_pixels, void* d_results, size_t fb_width, size_t fb_height,
+                                   size_t x, size_t y, size_t width, size_t height,
+                                   int launches, void* stream, float* ms_avg );
+
+/* ---- unit-level device entry points -----------------------------------------
+   Each runs the DEVICE implementation of one reference function over arrays of
+   independent inputs (host pointers; copied in and out). They exist so parity
+   tests can pin every stage of the path, not only whole images. */
+
+/* first n floats of the camera PCG for each seed (src/Terra.c:678-701); out[nseeds*n] */
+int terra_amd_unit_pcg ( const uint32_t* seeds, int nseeds, int n, float* out );
+/* stream keys (DESIGN.md "Randomness"): out3[i] = {seedA, stateB, incB} as uint64 */
+int terra_amd_unit_stream_keys ( uint64_t frame_seed, const uint64_t* pix, const uint64_t* samples_so_far, int n, uint64_t* out3 );
+/* terra_ray_aabb_intersection (src/Terra.c:851-878): hit[n], tmin[n], tmax[n] (t* written only on hit) */
+int terra_amd_unit_ray_aabb ( int n, const float* origins3, const float* dirs3, const float* boxes6, int* hit, float* tmin, float* tmax );
+/* watertight init+query (src/TerraGeometry.c:98-138,159-260): out8 = u,v,w,depth,px,py,pz,0 */
+int terra_amd_unit_watertight ( int n, const float* origins3, const float* dirs3, const float* tris9, int* hit, float* out8 );
+/* Moeller-Trumbore (src/Terra.c:880-922): out4 = t,px,py,pz */
+int terra_amd_unit_moller_trumbore ( int n, const float* origins3, const float* dirs3, const float* tris9, int* hit, float* out4 );
+/* terra_bvh_traverse on the committed scene (src/TerraBVH.c:250-310): prim = obj | tri<<8, point3 */
+int terra_amd_unit_bvh_traverse ( HTerraScene scene, int n, const float* origins3, const float* dirs3, int* found, uint32_t* prim, float* point3 );
+/* terra_scene_raycast + terra_surface_init (src/Terra.c:1623-1657,1726-1764):
+   obj[n] (-1 miss), tri[n], point3, surface47 = TerraShadingSurface as 47 floats */
+int terra_amd_unit_raycast ( HTerraScene scene, int n, const float* origins3, const float* dirs3, int* obj, int* tri, float* point3, float* surface47 );
+/* terra_trace (src/Terra.c:1039-1097) for n primary rays with explicit stream-B state: radiance3, rand_calls */
+int terra_amd_unit_trace ( HTerraScene scene, int n, const float* origins3, const float* dirs3, const uint64_t* stateB, const uint64_t* incB, float* radiance3, uint32_t* rand_calls );
+/* BSDF presets (src/TerraPresets.c:34-146). kind: 0 diffuse, 1 phong. surfaces47 in/out (Phong
+   writes the sample-pick slot). Per item: e[3], wo[3] -> wi[3], pdf, f[3] (pdf/eval at the sampled wi) */
+int terra_amd_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 );
+/* camera (src/Terra.c:1770-1799): dirs3 in world space for pixel (x,y), jitter, r1, r2 */
+int terra_amd_unit_camera ( const TerraCamera* camera, size_t fb_width, size_t fb_height, int n, const uint32_t* xy2, float jitter, const float* r2, float* dirs3 );
+/* tonemap (src/Terra.c:578-627): colors3 in place */
+int terra_amd_unit_tonemap ( int op, float gamma, int n, float* colors3 );
+/* device math: fn 0 sinf, 1 cosf, 2 powf(x,y), 3 acosf */
+int terra_amd_unit_math ( int fn, int n, const float* x, const float* y, float* out );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERRA_AMD_H */

@@ -1,0 +1,76 @@
+"""Builds terra_amd/libterra_amd.so (HIP kernels + C-ABI host side) for gfx950 with hipcc.
+
+In-tree build: the .so lands next to this file so it travels with the repo
+snapshot to the GPU box. Flags that matter for parity (DESIGN.md "Bit-faithful
+arithmetic"): no FMA contraction, IEEE f32 division/sqrt, no fast-math, f32
+denormals kept (hipcc default).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OUT = HERE / "libterra_amd.so"
+SOURCES = ["scene_host.cpp", "render_kernels.hip", "unit_kernels.hip"]
+HEADERS = ["dev_types.h", "dev_math.h", "rng.h", "trace_device.h", "kernels.h"]
+ARCH = os.environ.get("TERRA_AMD_ARCH", "gfx950")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+FLAGS = [
+    "-x", "hip", f"--offload-arch={ARCH}", "-std=c++17", "-O3", "-fPIC",
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+]
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    objdir = HERE / "build"
+    objdir.mkdir(exist_ok=True)
+    deps_common = [CSRC / h for h in HEADERS] + [HERE.parent / "include" / h for h in ("Terra.h", "TerraMath.h", "TerraPresets.h", "terra_amd.h")] + [Path(__file__)]
+    jobs = []
+    for src in SOURCES:
+        obj = objdir / (src + ".o")
+        if force or _stale(obj, [CSRC / src] + deps_common):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, flush=True)
+        return obj
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(compile_one, jobs))
+    objs = [objdir / (s + ".o") for s in SOURCES]
+    if force or jobs or _stale(OUT, objs):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", str(OUT), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

@@ -1,0 +1,110 @@
+// dev_types.h -- plain-data layouts shared by the host side (scene_host.cpp) and
+// the HIP kernels. Everything here is what actually sits in HBM / kernarg.
+//
+// HBM layout of a committed scene (one replica per GPU):
+//   nodes   : DevNode[n_nodes]     64 B each, same size as the reference node
+//             (reference src/TerraBVH.h:13-17) but with the two children packed as
+//             4 x 16-byte quads so a lane fetches a node with four dwordx4 loads.
+//   tris    : DevTri[n_tris]       48 B each: 36 B of vertex data (reference
+//             include/Terra.h:109-113) + the (object, triangle) reference in the
+//             pad lanes, so a leaf test is three aligned dwordx4 loads.
+//   props   : DevProps[n_tris]     64 B each: 60 B of vertex normals/texcoords
+//             (reference include/Terra.h:115-122) + 4 B pad.
+//   mats    : DevMaterial[n_objects]
+//   lights  : DevLight[n_lights], tri_area : float[n_tris] (only light triangles are read)
+// The "algorithmic bytes" of the roofline use the reference sizes (64/36/60),
+// not the padded ones (DESIGN.md "Roofline").
+#pragma once
+#include <stdint.h>
+
+#define TERRA_DEV_MAX_ATTR 8
+
+struct DevF3 { float x, y, z; };
+struct DevF4 { float x, y, z, w; };
+
+// child word: bit 31 clear -> inner node index; bit 31 set -> leaf, low 31 bits = global triangle index;
+// 0xFFFFFFFF -> empty slot (only in scenes with < 2 triangles)
+#define DEV_CHILD_LEAF  0x80000000u
+#define DEV_CHILD_EMPTY 0xFFFFFFFFu
+
+struct DevNode {
+    // q0 = min0.xyz, max0.x   q1 = max0.yz, min1.xy   q2 = min1.z, max1.xyz   q3 = child0, child1, prim0, prim1
+    // prim = reference leaf index (object | triangle << 8), kept so results carry the reference's TerraPrimitiveRef
+    float    min0[3], max0[3];
+    float    min1[3], max1[3];
+    uint32_t child[2];
+    uint32_t prim[2];
+};
+static_assert ( sizeof ( DevNode ) == 64, "DevNode must be 64 bytes" );
+
+struct DevTri {
+    float    a[3]; uint32_t object;
+    float    b[3]; uint32_t tri_in_object;
+    float    c[3]; uint32_t pad;
+};
+static_assert ( sizeof ( DevTri ) == 48, "DevTri must be 48 bytes" );
+
+struct DevProps {
+    float na[3], nb[3], nc[3];
+    float ta[2], tb[2], tc[2];
+    float pad;
+};
+static_assert ( sizeof ( DevProps ) == 64, "DevProps must be 64 bytes" );
+
+enum DevBsdfKind { kDevBsdfDiffuse = 0, kDevBsdfPhong = 1 };
+
+struct DevMaterial {
+    int32_t  bsdf;                 // DevBsdfKind
+    uint32_t attributes_count;
+    float    ior;
+    uint32_t first_tri;            // offset of the object's triangles in the soup
+    float    emissive[3];
+    uint32_t tri_count;
+    float    attributes[TERRA_DEV_MAX_ATTR][3];
+};
+
+struct DevLight {
+    uint32_t object;
+    uint32_t first_tri;
+    uint32_t tri_count;
+    float    area;
+};
+
+struct DevScene {
+    const DevNode*     nodes;
+    const DevTri*      tris;
+    const DevProps*    props;
+    const DevMaterial* mats;
+    const DevLight*    lights;
+    const float*       tri_area;
+    uint32_t n_nodes, n_tris, n_objects, n_lights;
+    uint32_t lights_triangles_count;
+    int32_t  max_stack;
+};
+
+// indices into the device counter array (uint64 each); mirrors TerraAmdStats
+enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrCount };
+
+struct DevRenderParams {
+    DevScene scene;
+    // camera (reference src/Terra.c:1770-1799): rot rows, position, tan(fov/2) (host double tan, rounded), aspect
+    float    cam_rot[9];
+    float    cam_pos[3];
+    float    tan_half_fov;
+    float    aspect;
+    float    jitter;
+    float    exposure;
+    float    gamma;
+    uint32_t fb_w, fb_h;
+    uint32_t x, y, w, h;            // rectangle to render
+    uint32_t tile_size, rank, world; // sharding: tiles t with t % world == rank (world == 1: everything)
+    uint32_t spp;                   // effective samples per pixel (after the stratified round-up)
+    uint32_t bounces;
+    int32_t  integrator;
+    int32_t  tonemap;
+    uint64_t frame_seed;
+    float*   pixels;                // 3 floats per pixel
+    void*    results;               // {float acc[3]; int samples} per pixel
+    uint32_t* rand_calls;           // optional
+    unsigned long long* counters;   // kCtrCount entries
+};

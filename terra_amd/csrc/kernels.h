@@ -1,0 +1,23 @@
+// kernels.h -- launchers implemented in the .hip files, called by the host side.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream );
+hipError_t terra_launch_tiles ( bool pack, float* pixels, void* results, uint32_t fb_w, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                                uint32_t tile, uint32_t rank, uint32_t world, float* packed, hipStream_t stream );
+
+// unit-level launchers: all pointers are DEVICE pointers, n items, synchronous semantics left to the caller
+hipError_t terra_unit_pcg ( const uint32_t* seeds, int nseeds, int n, float* out );
+hipError_t terra_unit_stream_keys ( uint64_t frame_seed, const uint64_t* pix, const uint64_t* k, int n, uint64_t* out3 );
+hipError_t terra_unit_ray_aabb ( int n, const float* o, const float* d, const float* boxes, int* hit, float* tmin, float* tmax );
+hipError_t terra_unit_watertight ( int n, const float* o, const float* d, const float* tris, int* hit, float* out8 );
+hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, const float* tris, int* hit, float* out4 );
+hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point );
+hipError_t terra_unit_raycast ( const DevScene& sc, int n, const float* o, const float* d, int* obj, int* tri, float* point, float* surface47 );
+hipError_t terra_unit_trace ( const DevScene& sc, int integrator, uint32_t bounces, int n, const float* o, const float* d,
+                              const uint64_t* stateB, const uint64_t* incB, float* radiance, uint32_t* rand_calls );
+hipError_t terra_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 );
+hipError_t terra_unit_camera ( const DevRenderParams& p, int n, const uint32_t* xy2, const float* r2, float* dirs3 );
+hipError_t terra_unit_tonemap ( int op, float gamma, int n, float* colors3 );
+hipError_t terra_unit_math ( int fn, int n, const float* x, const float* y, float* out );

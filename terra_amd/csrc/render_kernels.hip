@@ -1,0 +1,187 @@
+// render_kernels.hip -- the terra_render tile loop as a gfx950 kernel.
+//
+// Mapping (DESIGN.md "Kernel: terra_render_kernel"):
+//   * one LANE owns one pixel and walks its samples in order, so the per-pixel
+//     random streams are consumed in the reference's order and the radiance sum
+//     is accumulated in the reference's order (reference src/Terra.c:551-567);
+//   * one WAVE owns an 8x8 pixel packet, one 256-thread block a 16x16 region;
+//   * blocks are numbered tile-major (tile_size x tile_size tiles, row-major in the
+//     rectangle) so that the tile-sharded multi-GPU form is the same kernel with
+//     (rank, world) set (the reference shards tiles over threads the same way,
+//     satellite/src/Renderer.cpp:316-350);
+//   * a lane whose path ends starts its pixel's next sample in the same loop
+//     iteration ("path regeneration"), so the traversal loop always runs with
+//     every lane that still has samples;
+//   * the traversal stack lives in LDS, one column per lane (conflict free),
+//     sized from the tree (max_stack entries, computed at commit).
+#include <hip/hip_runtime.h>
+#include "trace_device.h"
+#include "kernels.h"
+
+struct DevResult { float acc[3]; int samples; };
+
+TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t pixels ) {
+    uint32_t v[9] = { c.rays, c.nodes, c.box_tests, c.tri_tests, c.hits, c.samples, c.rand_calls, c.attr_fetches, pixels };
+    #pragma unroll
+    for ( int k = 0; k < 9; ++k ) {
+        unsigned long long x = v[k];
+        #pragma unroll
+        for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
+        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &g[k], x );
+    }
+}
+
+template <int INTEGRATOR, bool COUNT>
+__global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams p ) {
+    extern __shared__ int lds_stack[];
+    const int tid = threadIdx.x;
+    int* stack = lds_stack + tid;
+    const int stride = 256;
+
+    // block -> (own tile, 16x16 block in tile) -> pixel
+    const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
+    const uint32_t k = blockIdx.x / bpt2, b = blockIdx.x - k * bpt2;
+    const uint32_t tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size;
+    const uint32_t t = p.rank + k * p.world;
+    const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+    const uint32_t bx = b % bpt, by = b / bpt;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t lx = tx * p.tile_size + bx * 16 + ( wave & 1 ) * 8 + ( lane & 7 );
+    const uint32_t ly = ty * p.tile_size + by * 16 + ( wave >> 1 ) * 8 + ( lane >> 3 );
+    const bool valid = lx < p.w && ly < p.h;
+    const uint32_t px = p.x + lx, py = p.y + ly;
+    const size_t pix = ( size_t ) py * p.fb_w + px;
+
+    DevResult* results = reinterpret_cast<DevResult*> ( p.results );
+    DevResult prior; prior.acc[0] = prior.acc[1] = prior.acc[2] = 0.f; prior.samples = 0;
+    if ( valid ) prior = results[pix];
+
+    PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) pix, ( uint64_t ) ( uint32_t ) prior.samples );
+    Counters c = counters_zero();
+
+    V3 acc = v3 ( 0, 0, 0 ), Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
+    Ray ray = make_ray ( v3 ( 0, 0, 0 ), v3 ( 0, 0, 1 ) );
+    uint32_t s = 0, bounce = 0;
+    bool alive = false;
+    const V3 cam_pos = v3p ( p.cam_pos );
+
+    while ( true ) {
+        if ( !alive ) {
+            if ( !valid || s == p.spp ) break;
+            float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
+            ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
+            Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++s;
+            if ( COUNT ) ++c.samples;
+        }
+        Surface sf;
+        RaycastResult h = scene_raycast<COUNT> ( p.scene, ray, sf, stack, stride, c );
+        bool end = !h.hit;
+        if ( h.hit ) {
+            V3 wo = neg ( ray.d );
+            Lo = Lo + integrate<INTEGRATOR, COUNT> ( p.scene, ray, sf, h.point, wo, throughput, bounce, rs.b, stack, stride, c );
+            float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
+            V3 wi = bsdf_sample ( sf, e0, e1, e2, wo );
+            float pdf = sel_max ( bsdf_pdf ( sf, wi, wo ), ( float ) 1e-4 );
+            V3 f = bsdf_eval ( sf, wi, wo ) * ( 1.f / pdf );
+            throughput = had ( throughput, f );
+            throughput = throughput * dot ( sf.normal, wi );
+            float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
+            float e3 = randf ( rs.b, c, COUNT );
+            if ( e3 > pr ) {
+                end = true;
+            } else {
+                throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+                ray = surface_ray ( sf, h.point, wi, 1.f );
+                ++bounce;
+                end = bounce > p.bounces;
+            }
+        }
+        if ( end ) { acc = acc + Lo; alive = false; }
+    }
+
+    if ( valid ) {
+        DevResult out;
+        out.acc[0] = acc.x + prior.acc[0]; out.acc[1] = acc.y + prior.acc[1]; out.acc[2] = acc.z + prior.acc[2];
+        out.samples = prior.samples + ( int ) p.spp;
+        results[pix] = out;
+        float n = ( float ) out.samples;
+        V3 color = v3 ( out.acc[0] / n, out.acc[1] / n, out.acc[2] / n ) * p.exposure;
+        color = tonemap ( color, p.tonemap, p.gamma );
+        p.pixels[3 * pix + 0] = color.x; p.pixels[3 * pix + 1] = color.y; p.pixels[3 * pix + 2] = color.z;
+        if ( p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
+    }
+    if ( COUNT ) wave_flush_counters ( c, p.counters, valid ? 1u : 0u );
+}
+
+// ---- launch -------------------------------------------------------------------
+
+static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank, uint32_t world ) {
+    uint32_t tiles = ( ( w + tile - 1 ) / tile ) * ( ( h + tile - 1 ) / tile );
+    return tiles > rank ? ( tiles - rank + world - 1 ) / world : 0;
+}
+
+template <int I>
+static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
+    hipLaunchKernelGGL ( ( terra_render_kernel<I, true> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
+    return hipGetLastError();
+}
+
+hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {
+    uint32_t bpt = p.tile_size / 16;
+    uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt;
+    if ( blocks == 0 ) return hipSuccess;
+    int depth = p.scene.max_stack < 1 ? 1 : p.scene.max_stack;
+    size_t lds = ( size_t ) depth * 256 * sizeof ( int );
+    switch ( p.integrator ) {
+        case 0: return launch_one<0> ( p, blocks, lds, stream );
+        case 1: return launch_one<1> ( p, blocks, lds, stream );
+        case 2: return launch_one<2> ( p, blocks, lds, stream );
+        case 3: return launch_one<3> ( p, blocks, lds, stream );
+        case 4: return launch_one<4> ( p, blocks, lds, stream );
+        case 5: return launch_one<5> ( p, blocks, lds, stream );
+        case 6: return launch_one<6> ( p, blocks, lds, stream );
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- tile pack / unpack for the multi-GPU gather -------------------------------
+// packed layout per tile: tile_size^2 pixels (12 B each, rows contiguous) then tile_size^2 results (16 B each)
+
+template <bool PACK>
+__global__ __launch_bounds__ ( 256 ) void terra_tiles_kernel ( float* pixels, DevResult* results, uint32_t fb_w, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                                                                  uint32_t tile, uint32_t rank, uint32_t world, float* packed ) {
+    const uint32_t tiles_x = ( w + tile - 1 ) / tile;
+    const uint32_t per_tile = tile * tile;
+    const uint32_t k = blockIdx.y;
+    const uint32_t t = rank + k * world;
+    const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+    float* tile_base = packed + ( size_t ) k * per_tile * 7;      // 3 + 4 floats per pixel
+    float* ppix = tile_base;
+    DevResult* pres = reinterpret_cast<DevResult*> ( tile_base + ( size_t ) per_tile * 3 );
+    for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < per_tile; i += gridDim.x * blockDim.x ) {
+        uint32_t lx = tx * tile + i % tile, ly = ty * tile + i / tile;
+        if ( lx >= w || ly >= h ) {
+            if ( PACK ) { ppix[3 * i] = ppix[3 * i + 1] = ppix[3 * i + 2] = 0.f; DevResult z = { { 0.f, 0.f, 0.f }, 0 }; pres[i] = z; }
+            continue;
+        }
+        size_t pix = ( size_t ) ( y + ly ) * fb_w + ( x + lx );
+        if ( PACK ) {
+            ppix[3 * i] = pixels[3 * pix]; ppix[3 * i + 1] = pixels[3 * pix + 1]; ppix[3 * i + 2] = pixels[3 * pix + 2];
+            pres[i] = results[pix];
+        } else {
+            pixels[3 * pix] = ppix[3 * i]; pixels[3 * pix + 1] = ppix[3 * i + 1]; pixels[3 * pix + 2] = ppix[3 * i + 2];
+            results[pix] = pres[i];
+        }
+    }
+}
+
+hipError_t terra_launch_tiles ( bool pack, float* pixels, void* results, uint32_t fb_w, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                                uint32_t tile, uint32_t rank, uint32_t world, float* packed, hipStream_t stream ) {
+    uint32_t n = own_tiles ( w, h, tile, rank, world );
+    if ( n == 0 ) return hipSuccess;
+    uint32_t per_tile = tile * tile;
+    dim3 grid ( ( per_tile + 255 ) / 256 < 64 ? ( per_tile + 255 ) / 256 : 64, n );
+    if ( pack ) hipLaunchKernelGGL ( terra_tiles_kernel<true>, grid, dim3 ( 256 ), 0, stream, pixels, ( DevResult* ) results, fb_w, x, y, w, h, tile, rank, world, packed );
+    else hipLaunchKernelGGL ( terra_tiles_kernel<false>, grid, dim3 ( 256 ), 0, stream, pixels, ( DevResult* ) results, fb_w, x, y, w, h, tile, rank, world, packed );
+    return hipGetLastError();
+}

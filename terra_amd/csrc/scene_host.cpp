@@ -1,0 +1,843 @@
+// scene_host.cpp -- host side of libterra_amd.so: the Terra.h scene/framebuffer API,
+// terra_scene_commit (host BVH build in the reference's tree layout + upload of the
+// flattened scene to HBM) and terra_render / terra_amd_render_device (kernel launch).
+//
+// Reference counterparts: scene lifecycle src/Terra.c:130-282, framebuffer :309-345,
+// attributes :287-304, render :512-635, BVH build src/TerraBVH.c:70-244 and
+// src/Terra.c:972-997, light list src/Terra.c:194-231.
+//
+// There is no CPU rendering path in this library. If the device is missing or a
+// material cannot run on it, the call fails loudly (terra_amd_last_error()).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/terra_amd.h"
+#include "../../include/TerraPresets.h"
+#include "dev_types.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------
+// error channel
+// ------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail ( TerraAmdStatus st, const char* fmt, ... ) {
+    char buf[512];
+    va_list a; va_start ( a, fmt ); vsnprintf ( buf, sizeof buf, fmt, a ); va_end ( a );
+    g_last_error = buf;
+    fprintf ( stderr, "[terra_amd] error: %s\n", buf );
+    return ( int ) st;
+}
+#define HIP_TRY(expr, st) do { hipError_t e_ = ( expr ); if ( e_ != hipSuccess ) return fail ( st, "%s: %s", #expr, hipGetErrorString ( e_ ) ); } while ( 0 )
+
+extern "C" const char* terra_amd_last_error ( void ) { return g_last_error.c_str(); }
+extern "C" void terra_amd_clear_error ( void ) { g_last_error.clear(); }
+
+// ------------------------------------------------------------------------------
+// device selection
+// ------------------------------------------------------------------------------
+static int g_device = 0;
+extern "C" int terra_amd_device_count ( void ) {
+    int n = 0;
+    if ( hipGetDeviceCount ( &n ) != hipSuccess ) return 0;
+    return n;
+}
+extern "C" int terra_amd_set_device ( int device ) {
+    int n = terra_amd_device_count();
+    if ( device < 0 || device >= n ) return fail ( kTerraAmdErrNoDevice, "device %d not available (%d visible)", device, n );
+    HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );
+    g_device = device;
+    return 0;
+}
+extern "C" int terra_amd_get_device ( void ) { return g_device; }
+
+// ------------------------------------------------------------------------------
+// system
+// ------------------------------------------------------------------------------
+extern "C" void* terra_malloc ( size_t size ) { return malloc ( size ); }
+extern "C" void* terra_realloc ( void* p, size_t size ) { return realloc ( p, size ); }
+extern "C" void  terra_free ( void* p ) { free ( p ); }
+extern "C" void  terra_log ( const char* str, ... ) { va_list a; va_start ( a, str ); vfprintf ( stdout, str, a ); va_end ( a ); }
+
+// ------------------------------------------------------------------------------
+// preset markers. The device BSDFs live in trace_device.h; these host symbols only
+// identify a preset. Calling them is an error: no CPU shading here.
+// ------------------------------------------------------------------------------
+static TerraFloat3 host_call_refused ( const char* what ) {
+    fail ( kTerraAmdErrUnsupported, "%s called on the host: BSDF presets execute on the device only", what );
+    TerraFloat3 z = { 0.f, 0.f, 0.f };
+    return z;
+}
+extern "C" {
+TerraFloat3 terra_bsdf_diffuse_sample ( const TerraShadingSurface*, float, float, float, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_diffuse_sample" ); }
+float       terra_bsdf_diffuse_pdf ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { host_call_refused ( "terra_bsdf_diffuse_pdf" ); return 0.f; }
+TerraFloat3 terra_bsdf_diffuse_eval ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_diffuse_eval" ); }
+TerraFloat3 terra_bsdf_phong_sample ( const TerraShadingSurface*, float, float, float, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_phong_sample" ); }
+float       terra_bsdf_phong_pdf ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { host_call_refused ( "terra_bsdf_phong_pdf" ); return 0.f; }
+TerraFloat3 terra_bsdf_phong_eval ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_phong_eval" ); }
+void terra_bsdf_diffuse_init ( TerraBSDF* b ) { b->sample = terra_bsdf_diffuse_sample; b->pdf = terra_bsdf_diffuse_pdf; b->eval = terra_bsdf_diffuse_eval; }
+void terra_bsdf_phong_init ( TerraBSDF* b ) { b->sample = terra_bsdf_phong_sample; b->pdf = terra_bsdf_phong_pdf; b->eval = terra_bsdf_phong_eval; }
+}
+
+// ------------------------------------------------------------------------------
+// attributes and textures (host data structures of the API; reference src/Terra.c:287-507)
+// ------------------------------------------------------------------------------
+extern "C" void terra_attribute_init_constant ( TerraAttribute* a, const TerraFloat3* v ) { a->state = nullptr; a->finalize = nullptr; a->eval = nullptr; a->value = *v; }
+extern "C" void terra_attribute_init_texture ( TerraAttribute* a, TerraTexture* t ) { a->state = t; a->eval = terra_texture_sample; a->finalize = terra_texture_finalize; }
+extern "C" void terra_attribute_init_cubemap ( TerraAttribute* a, TerraTexture* t ) { a->state = t; a->eval = terra_texture_sample_latlong; a->finalize = terra_texture_finalize; }
+
+extern "C" bool terra_texture_init ( TerraTexture* t, size_t w, size_t h, size_t comps, const void* data ) {
+    size_t bytes = w * h * comps;
+    t->pixels = malloc ( bytes ? bytes : 1 );
+    if ( !t->pixels ) return false;
+    memcpy ( t->pixels, data, bytes );
+    t->width = ( uint16_t ) w; t->height = ( uint16_t ) h; t->components = ( uint8_t ) comps; t->depth = 1;
+    return true;
+}
+extern "C" bool terra_texture_init_hdr ( TerraTexture* t, size_t w, size_t h, size_t comps, const float* data ) {
+    size_t bytes = sizeof ( float ) * w * h * comps;
+    t->pixels = malloc ( bytes ? bytes : 1 );
+    if ( !t->pixels ) return false;
+    memcpy ( t->pixels, data, bytes );
+    t->width = ( uint16_t ) w; t->height = ( uint16_t ) h; t->components = ( uint8_t ) comps; t->depth = 4;
+    return true;
+}
+extern "C" TerraFloat3 terra_texture_read ( TerraTexture* t, size_t x, size_t y ) {
+    TerraFloat3 out = { 0.f, 0.f, 0.f };
+    if ( !t || !t->pixels || !t->width || !t->height ) return out;
+    const size_t W = t->width, H = t->height;
+    if ( t->address_mode == kTerraTextureAddressClamp ) { x = std::min ( x, W - 1 ); y = std::min ( y, H - 1 ); }
+    else if ( t->address_mode == kTerraTextureAddressWrap ) { x %= W; y %= H; }
+    else if ( ( x / W ) % 2 == 0 ) { x %= W; y %= H; }
+    else { x = W - ( x % W ); y = H - ( y % H ); x = std::min ( x, W - 1 ); y = std::min ( y, H - 1 ); }
+    const size_t texel = ( y * W + x ) * t->components;
+    if ( t->depth == 1 ) {
+        const uint8_t* p = ( const uint8_t* ) t->pixels + texel;
+        out.x = p[0] / 255.f; out.y = t->components > 1 ? p[1] / 255.f : 0.f; out.z = t->components > 2 ? p[2] / 255.f : 0.f;
+    } else if ( t->depth == 4 ) {
+        const float* p = ( const float* ) t->pixels + texel;
+        out.x = p[0]; out.y = t->components > 1 ? p[1] : 0.f; out.z = t->components > 2 ? p[2] : 0.f;
+    }
+    return out;
+}
+extern "C" TerraFloat3 terra_texture_sample ( void* tex, const void* uvp, const void* ) {
+    TerraTexture* t = ( TerraTexture* ) tex; const TerraFloat2* uv = ( const TerraFloat2* ) uvp;
+    size_t ix = ( size_t ) uv->x, iy = ( size_t ) uv->y;
+    if ( t->filter == kTerraFilterPoint ) return terra_texture_read ( t, ix, iy );
+    TerraFloat3 s = { 0.f, 0.f, 0.f };
+    if ( t->filter == kTerraFilterBilinear ) {
+        size_t x2 = std::min<size_t> ( ix + 1, ( size_t ) t->width - 1 ), y2 = std::min<size_t> ( iy + 1, ( size_t ) t->height - 1 );
+        TerraFloat3 n1 = terra_texture_read ( t, ix, iy ), n2 = terra_texture_read ( t, x2, iy );
+        TerraFloat3 n3 = terra_texture_read ( t, ix, y2 ), n4 = terra_texture_read ( t, x2, y2 );
+        float wu = uv->x - ix, wv = uv->y - iy, wou = 1.f - wu, wov = 1.f - wv;
+        s.x = ( n1.x * wou + n2.x * wu ) * wov + ( n3.x * wou + n4.x * wu ) * wv;
+        s.y = ( n1.y * wou + n2.y * wu ) * wov + ( n3.y * wou + n4.y * wu ) * wv;
+        s.z = ( n1.z * wou + n2.z * wu ) * wov + ( n3.z * wou + n4.z * wu ) * wv;
+    }
+    return s;
+}
+extern "C" TerraFloat3 terra_texture_sample_latlong ( void* tex, const void* dirp, const void* ) {
+    TerraTexture* t = ( TerraTexture* ) tex;
+    TerraFloat3 d = terra_normf3 ( ( const TerraFloat3* ) dirp );
+    float theta = acosf ( d.y );
+    float phi = atan2f ( d.z, d.x ) + terra_PI;
+    size_t u = ( size_t ) ( ( phi / ( 2 * terra_PI ) ) * t->width );
+    size_t v = ( size_t ) ( ( theta / ( terra_PI ) ) * t->height );
+    return terra_texture_read ( t, u, v );
+}
+extern "C" void terra_texture_destroy ( TerraTexture* t ) { if ( t ) { free ( t->pixels ); t->pixels = nullptr; } }
+extern "C" void terra_texture_finalize ( void* tex ) {
+    TerraTexture* t = ( TerraTexture* ) tex;
+    if ( !t || !t->pixels ) return;
+    size_t n = ( size_t ) t->width * t->height * t->components;
+    if ( t->depth == 1 ) { uint8_t* p = ( uint8_t* ) t->pixels; for ( size_t i = 0; i < n; ++i ) p[i] = ( uint8_t ) ( powf ( p[i] / 255.f, 2.2f ) * 255 ); }
+    else if ( t->depth == 4 ) { float* p = ( float* ) t->pixels; for ( size_t i = 0; i < n; ++i ) p[i] = powf ( p[i], 2.2f ); }
+}
+
+// ------------------------------------------------------------------------------
+// framebuffer: pinned host memory when a device is present (faster tile copies)
+// ------------------------------------------------------------------------------
+static std::mutex g_pinned_lock;
+static std::unordered_set<void*> g_pinned;
+
+static void* fb_alloc ( size_t bytes ) {
+    void* p = nullptr;
+    if ( terra_amd_device_count() > 0 && hipHostMalloc ( &p, bytes, hipHostMallocDefault ) == hipSuccess && p ) {
+        std::lock_guard<std::mutex> g ( g_pinned_lock );
+        g_pinned.insert ( p );
+        return p;
+    }
+    ( void ) hipGetLastError();
+    return malloc ( bytes );
+}
+static void fb_free ( void* p ) {
+    if ( !p ) return;
+    bool pinned;
+    { std::lock_guard<std::mutex> g ( g_pinned_lock ); pinned = g_pinned.erase ( p ) > 0; }
+    if ( pinned ) ( void ) hipHostFree ( p ); else free ( p );
+}
+extern "C" bool terra_framebuffer_create ( TerraFramebuffer* fb, size_t w, size_t h ) {
+    if ( !fb || w == 0 || h == 0 ) return false;
+    fb->width = w; fb->height = h;
+    fb->pixels = ( TerraFloat3* ) fb_alloc ( sizeof ( TerraFloat3 ) * w * h );
+    fb->results = ( TerraRawIntegrationResult* ) fb_alloc ( sizeof ( TerraRawIntegrationResult ) * w * h );
+    if ( !fb->pixels || !fb->results ) return false;
+    terra_framebuffer_clear ( fb );
+    return true;
+}
+extern "C" void terra_framebuffer_clear ( TerraFramebuffer* fb ) {
+    memset ( fb->pixels, 0, sizeof ( TerraFloat3 ) * fb->width * fb->height );
+    memset ( fb->results, 0, sizeof ( TerraRawIntegrationResult ) * fb->width * fb->height );
+}
+extern "C" void terra_framebuffer_destroy ( TerraFramebuffer* fb ) {
+    if ( !fb ) return;
+    fb_free ( fb->results ); fb_free ( fb->pixels );
+    fb->results = nullptr; fb->pixels = nullptr;
+}
+
+// ------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------
+struct HostNode { TerraAABB aabb[2]; int32_t index[2]; int32_t type[2]; };   // reference node layout (src/TerraBVH.h:13-17)
+static_assert ( sizeof ( HostNode ) == 64, "reference node is 64 bytes" );
+
+struct HostLight { uint32_t object; float area; TerraFloat3 power; };
+
+struct Scene {
+    TerraSceneOptions opts, new_opts;
+    TerraObject* objects = nullptr; size_t objects_pop = 0, objects_cap = 0;
+    bool dirty_objects = true, dirty_lights = true, committed = false, device_ok = false;
+    uint64_t frame_seed = 0x5EED0001ull;
+    int device = 0;
+    // host mirrors
+    std::vector<HostNode> nodes; int max_stack = 1;
+    std::vector<HostLight> lights; size_t lights_triangles_count = 0;
+    std::vector<uint32_t> first_tri;     // per object
+    // device replica
+    DevScene dev; void* d_blob = nullptr; size_t d_bytes = 0;
+    unsigned long long* d_counters = nullptr;
+    uint64_t launches = 0;
+    std::string commit_error;
+};
+
+static Scene* S ( HTerraScene h ) { return ( Scene* ) h; }
+
+extern "C" HTerraScene terra_scene_create ( void ) {
+    Scene* s = new Scene();
+    memset ( &s->opts, 0, sizeof s->opts ); memset ( &s->new_opts, 0, sizeof s->new_opts ); memset ( &s->dev, 0, sizeof s->dev );
+    s->objects_cap = 64;
+    s->objects = ( TerraObject* ) malloc ( sizeof ( TerraObject ) * s->objects_cap );
+    s->device = g_device;
+    return s;
+}
+extern "C" TerraObject* terra_scene_add_object ( HTerraScene h, size_t n ) {
+    Scene* s = S ( h );
+    if ( s->objects_pop == s->objects_cap ) {
+        s->objects_cap *= 2;
+        s->objects = ( TerraObject* ) realloc ( s->objects, sizeof ( TerraObject ) * s->objects_cap );
+    }
+    TerraObject* o = &s->objects[s->objects_pop++];
+    memset ( o, 0, sizeof *o );
+    o->triangles = ( TerraTriangle* ) malloc ( sizeof ( TerraTriangle ) * ( n ? n : 1 ) );
+    o->properties = ( TerraTriangleProperties* ) malloc ( sizeof ( TerraTriangleProperties ) * ( n ? n : 1 ) );
+    o->triangles_count = n;
+    s->dirty_objects = true; s->dirty_lights = true; s->committed = false;
+    return o;
+}
+extern "C" size_t terra_scene_count_objects ( HTerraScene h ) { return S ( h )->objects_pop; }
+extern "C" TerraSceneOptions* terra_scene_get_options ( HTerraScene h ) { return &S ( h )->new_opts; }
+extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
+extern "C" uint64_t terra_amd_get_frame_seed ( HTerraScene h ) { return S ( h )->frame_seed; }
+
+static void release_device ( Scene* s ) {
+    if ( s->d_blob || s->d_counters ) {
+        ( void ) hipSetDevice ( s->device );
+        if ( s->d_blob ) ( void ) hipFree ( s->d_blob );
+        if ( s->d_counters ) ( void ) hipFree ( s->d_counters );
+    }
+    s->d_blob = nullptr; s->d_counters = nullptr; s->d_bytes = 0; s->device_ok = false;
+    memset ( &s->dev, 0, sizeof s->dev );
+}
+extern "C" void terra_scene_clear ( HTerraScene h ) {
+    Scene* s = S ( h );
+    for ( size_t i = 0; i < s->objects_pop; ++i ) { free ( s->objects[i].triangles ); free ( s->objects[i].properties ); }
+    s->objects_pop = 0;
+    s->lights.clear();
+    s->dirty_objects = true; s->dirty_lights = true; s->committed = false;
+}
+extern "C" void terra_scene_destroy ( HTerraScene h ) {
+    Scene* s = S ( h );
+    if ( !s ) return;
+    terra_scene_clear ( h );
+    release_device ( s );
+    free ( s->objects );
+    delete s;
+}
+
+// ---- BVH build: the reference's tree ------------------------
+// Per-triangle boxes inflated by 1e-4 (double add, rounded), one stable sort by
+// DESCENDING box-centre x (what the reference's bool comparator produces under
+// glibc's merge sort), sweep SAH per range with the first minimum winning, inner
+// boxes growing their max by 1e-4 per merge, children numbered left-then-right when
+// the parent is expanded and the right range expanded first (LIFO task stack).
+namespace bvh {
+struct Volume { TerraAABB box; uint32_t index; };
+
+static inline float fmin_sel ( float a, float b ) { return a < b ? a : b; }
+static inline float fmax_sel ( float a, float b ) { return a > b ? a : b; }
+static TerraAABB empty_box() { TerraAABB b; b.min = { FLT_MAX, FLT_MAX, FLT_MAX }; b.max = { -FLT_MAX, -FLT_MAX, -FLT_MAX }; return b; }
+static void grow_by_triangle ( TerraAABB& b, const TerraTriangle& t ) {
+    const double eps = 1e-4;
+    b.min.x = ( float ) ( ( double ) fmin_sel ( fmin_sel ( fmin_sel ( b.min.x, t.a.x ), t.b.x ), t.c.x ) - eps );
+    b.min.y = ( float ) ( ( double ) fmin_sel ( fmin_sel ( fmin_sel ( b.min.y, t.a.y ), t.b.y ), t.c.y ) - eps );
+    b.min.z = ( float ) ( ( double ) fmin_sel ( fmin_sel ( fmin_sel ( b.min.z, t.a.z ), t.b.z ), t.c.z ) - eps );
+    b.max.x = ( float ) ( ( double ) fmax_sel ( fmax_sel ( fmax_sel ( b.max.x, t.a.x ), t.b.x ), t.c.x ) + eps );
+    b.max.y = ( float ) ( ( double ) fmax_sel ( fmax_sel ( fmax_sel ( b.max.y, t.a.y ), t.b.y ), t.c.y ) + eps );
+    b.max.z = ( float ) ( ( double ) fmax_sel ( fmax_sel ( fmax_sel ( b.max.z, t.a.z ), t.b.z ), t.c.z ) + eps );
+}
+static void grow_by_box ( TerraAABB& b, const TerraAABB& o ) {
+    const double eps = 1e-4;
+    b.min.x = fmin_sel ( b.min.x, o.min.x ); b.min.y = fmin_sel ( b.min.y, o.min.y ); b.min.z = fmin_sel ( b.min.z, o.min.z );
+    b.max.x = ( float ) ( ( double ) fmax_sel ( b.max.x, o.max.x ) + eps );
+    b.max.y = ( float ) ( ( double ) fmax_sel ( b.max.y, o.max.y ) + eps );
+    b.max.z = ( float ) ( ( double ) fmax_sel ( b.max.z, o.max.z ) + eps );
+}
+static float area ( const TerraAABB& b ) {
+    float w = b.max.x - b.min.x, h = b.max.y - b.min.y, d = b.max.z - b.min.z;
+    return 2 * ( w * d + w * h + d * h );
+}
+static float centre_x ( const TerraAABB& b ) { return ( b.min.x + b.max.x ) / 2; }
+
+static void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nodes, int& max_stack ) {
+    size_t n = 0;
+    for ( size_t j = 0; j < nobj; ++j ) n += objects[j].triangles_count;
+    std::vector<Volume> vol ( n );
+    TerraAABB scene_box = empty_box();
+    size_t p = 0;
+    for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < objects[j].triangles_count; ++i, ++p ) {
+        vol[p].box = empty_box();
+        grow_by_triangle ( scene_box, objects[j].triangles[i] );     // the scene box shrinks/grows by eps per triangle, as in the reference
+        grow_by_triangle ( vol[p].box, objects[j].triangles[i] );
+        vol[p].index = ( uint32_t ) ( ( int ) j | ( ( int ) i << 8 ) );
+    }
+    nodes.assign ( n > 1 ? n - 1 : 1, HostNode() );
+    memset ( nodes.data(), 0, nodes.size() * sizeof ( HostNode ) );
+    max_stack = 1;
+    if ( n < 2 ) {      // the reference cannot build these; emit a root with one (or no) leaf
+        nodes[0].type[0] = n == 1 ? 1 : 0; nodes[0].type[1] = 0;
+        if ( n == 1 ) { nodes[0].aabb[0] = vol[0].box; nodes[0].index[0] = ( int32_t ) vol[0].index; }
+        return;
+    }
+    std::stable_sort ( vol.begin(), vol.end(), [] ( const Volume & l, const Volume & r ) { return centre_x ( l.box ) > centre_x ( r.box ); } );
+    struct Task { int start, end, node; TerraAABB container; };
+    std::vector<Task> todo;
+    std::vector<float> la ( n ), ra ( n );
+    todo.push_back ( { 0, ( int ) n, 0, scene_box } );
+    int next_node = 1;
+    while ( !todo.empty() ) {
+        Task t = todo.back(); todo.pop_back();
+        const int cnt = t.end - t.start;
+        const Volume* v = vol.data() + t.start;
+        const float container_area = area ( t.container );
+        TerraAABB acc = empty_box();
+        for ( int i = 0; i < cnt; ++i ) { grow_by_box ( acc, v[i].box ); la[i] = area ( acc ); }
+        acc = empty_box();
+        for ( int i = cnt - 1; i >= 0; --i ) { grow_by_box ( acc, v[i].box ); ra[i] = area ( acc ); }
+        float best_cost = FLT_MAX; int best = -1;
+        for ( int i = 0; i < cnt; ++i ) {
+            const int lc = i + 1, rc = cnt - lc;
+            float cost = lc * la[i] / container_area + rc * ra[i] / container_area;
+            if ( cost < best_cost ) { best_cost = cost; best = i; }
+        }
+        if ( best < 0 ) best = 0;
+        if ( best > cnt - 2 ) best = cnt - 2;
+        const int split = best + t.start;
+        HostNode& nd = nodes[t.node];
+        if ( split == t.start ) {
+            nd.type[0] = 1; nd.aabb[0] = vol[t.start].box; nd.index[0] = ( int32_t ) vol[t.start].index;
+        } else {
+            TerraAABB b = empty_box();
+            for ( int i = t.start; i <= split; ++i ) grow_by_box ( b, vol[i].box );
+            nd.type[0] = -1; nd.aabb[0] = b; nd.index[0] = next_node;
+            todo.push_back ( { t.start, split + 1, next_node, b } );
+            ++next_node;
+        }
+        if ( split == t.end - 2 ) {
+            nd.type[1] = 1; nd.aabb[1] = vol[t.end - 1].box; nd.index[1] = ( int32_t ) vol[t.end - 1].index;
+        } else {
+            TerraAABB b = empty_box();
+            for ( int i = split + 1; i < t.end; ++i ) grow_by_box ( b, vol[i].box );
+            nd.type[1] = -1; nd.aabb[1] = b; nd.index[1] = next_node;
+            todo.push_back ( { split + 1, t.end, next_node, b } );
+            ++next_node;
+        }
+    }
+    nodes.resize ( ( size_t ) next_node );
+    // stack entries a ray can need: replay the traversal's push/pop order with every box hit
+    std::vector<int> st; st.reserve ( 64 ); st.push_back ( 0 );
+    while ( !st.empty() ) {
+        const HostNode& nd = nodes[ ( size_t ) st.back()]; st.pop_back();
+        for ( int i = 0; i < 2; ++i ) if ( nd.type[i] == -1 ) { st.push_back ( nd.index[i] ); max_stack = std::max ( max_stack, ( int ) st.size() ); }
+    }
+}
+} // namespace bvh
+
+static float triangle_area ( const TerraTriangle& t ) {
+    TerraFloat3 ab = terra_subf3 ( &t.b, &t.a ), ac = terra_subf3 ( &t.c, &t.a );
+    TerraFloat3 c = terra_crossf3 ( &ab, &ac );
+    return terra_lenf3 ( &c ) / 2;
+}
+
+static bool is_diffuse ( const TerraBSDF& b ) { return b.sample == terra_bsdf_diffuse_sample && b.pdf == terra_bsdf_diffuse_pdf && b.eval == terra_bsdf_diffuse_eval; }
+static bool is_phong ( const TerraBSDF& b ) { return b.sample == terra_bsdf_phong_sample && b.pdf == terra_bsdf_phong_pdf && b.eval == terra_bsdf_phong_eval; }
+
+// validates that every material can run on the device and uploads the flattened scene
+static int upload_scene ( Scene* s ) {
+    const size_t nobj = s->objects_pop;
+    if ( nobj > 256 ) return fail ( kTerraAmdErrUnsupported, "%zu objects: the primitive reference holds 8 bits of object index (include/Terra.h:195-198)", nobj );
+    size_t ntri = 0;
+    s->first_tri.assign ( nobj, 0 );
+    for ( size_t j = 0; j < nobj; ++j ) { s->first_tri[j] = ( uint32_t ) ntri; ntri += s->objects[j].triangles_count; }
+    if ( ntri >= 0x7fffffffu ) return fail ( kTerraAmdErrUnsupported, "too many triangles" );
+    std::vector<DevMaterial> mats ( nobj ? nobj : 1 );
+    memset ( mats.data(), 0, mats.size() * sizeof ( DevMaterial ) );
+    for ( size_t j = 0; j < nobj; ++j ) {
+        const TerraMaterial& m = s->objects[j].material;
+        DevMaterial& d = mats[j];
+        if ( is_diffuse ( m.bsdf ) ) d.bsdf = kDevBsdfDiffuse;
+        else if ( is_phong ( m.bsdf ) ) d.bsdf = kDevBsdfPhong;
+        else return fail ( kTerraAmdErrUnsupported, "object %zu: BSDF function pointers are not a terra_bsdf_*_init preset of this library; host callbacks cannot run on the device", j );
+        if ( m.attributes_count > TERRA_MATERIAL_MAX_ATTRIBUTES ) return fail ( kTerraAmdErrBadArgument, "object %zu: attributes_count %zu > %d", j, m.attributes_count, TERRA_MATERIAL_MAX_ATTRIBUTES );
+        if ( m.emissive.state != nullptr ) return fail ( kTerraAmdErrUnsupported, "object %zu: textured emissive is not supported on the device yet", j );
+        for ( size_t a = 0; a < m.attributes_count; ++a ) {
+            if ( m.attributes[a].state != nullptr ) return fail ( kTerraAmdErrUnsupported, "object %zu attribute %zu: textured/procedural attributes are not supported on the device yet", j, a );
+            d.attributes[a][0] = m.attributes[a].value.x; d.attributes[a][1] = m.attributes[a].value.y; d.attributes[a][2] = m.attributes[a].value.z;
+        }
+        d.attributes_count = ( uint32_t ) m.attributes_count;
+        d.ior = m.ior;
+        d.first_tri = s->first_tri[j]; d.tri_count = ( uint32_t ) s->objects[j].triangles_count;
+        d.emissive[0] = m.emissive.value.x; d.emissive[1] = m.emissive.value.y; d.emissive[2] = m.emissive.value.z;
+    }
+    // flatten
+    std::vector<DevTri> tris ( ntri ? ntri : 1 );
+    std::vector<DevProps> props ( ntri ? ntri : 1 );
+    std::vector<float> tri_area ( ntri ? ntri : 1, 0.f );
+    for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count; ++i ) {
+        const TerraTriangle& t = s->objects[j].triangles[i]; const TerraTriangleProperties& q = s->objects[j].properties[i];
+        DevTri& d = tris[s->first_tri[j] + i];
+        d.a[0] = t.a.x; d.a[1] = t.a.y; d.a[2] = t.a.z; d.object = ( uint32_t ) j;
+        d.b[0] = t.b.x; d.b[1] = t.b.y; d.b[2] = t.b.z; d.tri_in_object = ( uint32_t ) i;
+        d.c[0] = t.c.x; d.c[1] = t.c.y; d.c[2] = t.c.z; d.pad = 0;
+        DevProps& e = props[s->first_tri[j] + i];
+        memcpy ( e.na, &q.normal_a, 12 ); memcpy ( e.nb, &q.normal_b, 12 ); memcpy ( e.nc, &q.normal_c, 12 );
+        memcpy ( e.ta, &q.texcoord_a, 8 ); memcpy ( e.tb, &q.texcoord_b, 8 ); memcpy ( e.tc, &q.texcoord_c, 8 );
+        e.pad = 0.f;
+    }
+    std::vector<DevLight> lights ( s->lights.size() ? s->lights.size() : 1 );
+    for ( size_t l = 0; l < s->lights.size(); ++l ) {
+        const uint32_t o = s->lights[l].object;
+        lights[l].object = o; lights[l].first_tri = s->first_tri[o]; lights[l].tri_count = ( uint32_t ) s->objects[o].triangles_count; lights[l].area = s->lights[l].area;
+        for ( size_t i = 0; i < s->objects[o].triangles_count; ++i ) tri_area[s->first_tri[o] + i] = triangle_area ( s->objects[o].triangles[i] );
+    }
+    std::vector<DevNode> nodes ( s->nodes.size() );
+    for ( size_t k = 0; k < s->nodes.size(); ++k ) {
+        const HostNode& h = s->nodes[k]; DevNode& d = nodes[k];
+        memcpy ( d.min0, &h.aabb[0].min, 12 ); memcpy ( d.max0, &h.aabb[0].max, 12 );
+        memcpy ( d.min1, &h.aabb[1].min, 12 ); memcpy ( d.max1, &h.aabb[1].max, 12 );
+        for ( int c = 0; c < 2; ++c ) {
+            if ( h.type[c] == -1 ) { d.child[c] = ( uint32_t ) h.index[c]; d.prim[c] = 0; }
+            else if ( h.type[c] == 1 ) {
+                uint32_t obj = ( uint32_t ) h.index[c] & 0xffu, tri = ( uint32_t ) h.index[c] >> 8;
+                d.child[c] = DEV_CHILD_LEAF | ( s->first_tri[obj] + tri ); d.prim[c] = ( uint32_t ) h.index[c];
+            } else { d.child[c] = DEV_CHILD_EMPTY; d.prim[c] = 0; }
+        }
+    }
+    // one blob, 256-byte aligned sections
+    auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
+    size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
+    size_t o_mats = align ( o_props + props.size() * sizeof ( DevProps ) ), o_lights = align ( o_mats + mats.size() * sizeof ( DevMaterial ) );
+    size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), total = align ( o_area + tri_area.size() * sizeof ( float ) );
+
+    release_device ( s );
+    s->device = g_device;
+    if ( terra_amd_device_count() <= 0 ) return fail ( kTerraAmdErrNoDevice, "no HIP device visible: terra_scene_commit built the host tree but cannot upload; terra_render will fail" );
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMalloc ( &s->d_blob, total ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMalloc ( ( void** ) &s->d_counters, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemset ( s->d_counters, 0, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
+    char* base = ( char* ) s->d_blob;
+    HIP_TRY ( hipMemcpy ( base + o_nodes, nodes.data(), nodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( base + o_tris, tris.data(), tris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( base + o_props, props.data(), props.size() * sizeof ( DevProps ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( base + o_mats, mats.data(), mats.size() * sizeof ( DevMaterial ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( base + o_lights, lights.data(), lights.size() * sizeof ( DevLight ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( base + o_area, tri_area.data(), tri_area.size() * sizeof ( float ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    s->d_bytes = total;
+    s->dev.nodes = ( const DevNode* ) ( base + o_nodes ); s->dev.tris = ( const DevTri* ) ( base + o_tris ); s->dev.props = ( const DevProps* ) ( base + o_props );
+    s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
+    s->dev.n_nodes = ( uint32_t ) nodes.size(); s->dev.n_tris = ( uint32_t ) ntri; s->dev.n_objects = ( uint32_t ) nobj; s->dev.n_lights = ( uint32_t ) s->lights.size();
+    s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
+    s->device_ok = true;
+    return 0;
+}
+
+extern "C" void terra_scene_commit ( HTerraScene h ) {
+    Scene* s = S ( h );
+    const bool rebuild = s->dirty_objects || s->opts.accelerator != s->new_opts.accelerator || s->nodes.empty();
+    s->opts = s->new_opts;
+    if ( rebuild ) bvh::build ( s->objects, s->objects_pop, s->nodes, s->max_stack );
+    const bool relight = s->dirty_lights || rebuild;
+    if ( relight ) {
+        s->lights.clear();
+        s->lights_triangles_count = 0;      // the reference never resets this (src/Terra.c:228); see DESIGN.md deviations
+        for ( size_t i = 0; i < s->objects_pop; ++i ) {
+            const TerraAttribute& em = s->objects[i].material.emissive;
+            TerraFloat3 e = em.value;
+            if ( em.state != nullptr ) continue;    // rejected in upload_scene with a message
+            if ( e.x == 0 && e.y == 0 && e.z == 0 ) continue;
+            float area = 0;
+            for ( size_t j = 0; j < s->objects[i].triangles_count; ++j ) area += triangle_area ( s->objects[i].triangles[j] );
+            HostLight l; l.object = ( uint32_t ) i; l.area = area; l.power = terra_mulf3 ( &e, area * terra_PI );
+            s->lights.push_back ( l );
+            s->lights_triangles_count += s->objects[i].triangles_count;
+        }
+    }
+    s->dirty_objects = false; s->dirty_lights = false;
+    s->committed = true;
+    s->commit_error.clear();
+    if ( s->opts.environment_map.state != nullptr ) { fail ( kTerraAmdErrUnsupported, "textured environment map is not supported on the device yet" ); s->commit_error = g_last_error; s->device_ok = false; return; }
+    // options travel as kernel arguments; geometry/material/light changes need a new replica
+    if ( ( rebuild || relight || !s->device_ok ) && upload_scene ( s ) != 0 ) { s->commit_error = g_last_error; s->device_ok = false; }
+}
+
+extern "C" int terra_amd_scene_info ( HTerraScene h, TerraAmdSceneInfo* out ) {
+    Scene* s = S ( h );
+    if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "scene not committed" );
+    size_t ntri = 0; for ( size_t j = 0; j < s->objects_pop; ++j ) ntri += s->objects[j].triangles_count;
+    out->triangles = ( uint32_t ) ntri; out->nodes = ( uint32_t ) s->nodes.size(); out->objects = ( uint32_t ) s->objects_pop; out->lights = ( uint32_t ) s->lights.size();
+    out->lights_triangles_count = ( uint32_t ) s->lights_triangles_count; out->max_stack = s->max_stack; out->device_bytes = s->d_bytes;
+    return 0;
+}
+extern "C" int terra_amd_scene_bvh_nodes ( HTerraScene h, void* out, int capacity ) {
+    Scene* s = S ( h );
+    if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "scene not committed" );
+    int n = ( int ) s->nodes.size();
+    if ( out && capacity >= n ) memcpy ( out, s->nodes.data(), ( size_t ) n * sizeof ( HostNode ) );
+    return n;
+}
+extern "C" int terra_amd_get_stats ( HTerraScene h, TerraAmdStats* out ) {
+    Scene* s = S ( h );
+    memset ( out, 0, sizeof *out );
+    if ( !s->device_ok ) return fail ( kTerraAmdErrNotCommitted, "scene has no device replica" );
+    unsigned long long c[kCtrCount];
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( c, s->d_counters, sizeof c, hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
+    out->rays = c[kCtrRays]; out->nodes = c[kCtrNodes]; out->box_tests = c[kCtrBoxTests]; out->tri_tests = c[kCtrTriTests]; out->hits = c[kCtrHits];
+    out->samples = c[kCtrSamples]; out->rand_calls = c[kCtrRandCalls]; out->attr_fetches = c[kCtrAttrFetches]; out->pixels = c[kCtrPixels]; out->launches = s->launches;
+    return 0;
+}
+extern "C" int terra_amd_reset_stats ( HTerraScene h ) {
+    Scene* s = S ( h );
+    if ( !s->device_ok ) return fail ( kTerraAmdErrNotCommitted, "scene has no device replica" );
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemset ( s->d_counters, 0, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
+    s->launches = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// render
+// ------------------------------------------------------------------------------
+static uint32_t effective_spp ( const TerraSceneOptions& o ) {
+    size_t spp = o.samples_per_pixel;
+    if ( o.sampling_method == kTerraSamplingMethodStratified ) {      // reference src/Terra.c:519-527
+        size_t cur = o.strata * o.strata;
+        while ( spp > cur && cur > 1 ) cur *= cur;
+        if ( cur >= spp ) spp = cur;
+    }
+    return ( uint32_t ) spp;
+}
+
+static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t fb_h, size_t x, size_t y, size_t w, size_t h,
+                         size_t tile, int rank, int world, DevRenderParams& p ) {
+    if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "terra_scene_commit has not run since the scene changed" );
+    if ( !s->device_ok ) return fail ( kTerraAmdErrNoDevice, "scene has no device replica: %s", s->commit_error.c_str() );
+    if ( !cam || w == 0 || h == 0 || x + w > fb_w || y + h > fb_h ) return fail ( kTerraAmdErrBadArgument, "bad tile rectangle %zu,%zu %zux%zu in %zux%zu", x, y, w, h, fb_w, fb_h );
+    if ( tile == 0 || tile % 16 != 0 ) return fail ( kTerraAmdErrBadArgument, "tile_size %zu must be a positive multiple of 16", tile );
+    if ( world < 1 || rank < 0 || rank >= world ) return fail ( kTerraAmdErrBadArgument, "bad shard %d/%d", rank, world );
+    memset ( &p, 0, sizeof p );
+    p.scene = s->dev;
+    // camera frame, reference src/Terra.c:1770-1781
+    TerraFloat3 z = terra_normf3 ( &cam->direction );
+    TerraFloat3 xa = terra_crossf3 ( &cam->up, &z ); xa = terra_normf3 ( &xa );
+    TerraFloat3 ya = terra_crossf3 ( &z, &xa );
+    p.cam_rot[0] = xa.x; p.cam_rot[1] = ya.x; p.cam_rot[2] = z.x;
+    p.cam_rot[3] = xa.y; p.cam_rot[4] = ya.y; p.cam_rot[5] = z.y;
+    p.cam_rot[6] = xa.z; p.cam_rot[7] = ya.z; p.cam_rot[8] = z.z;
+    p.cam_pos[0] = cam->position.x; p.cam_pos[1] = cam->position.y; p.cam_pos[2] = cam->position.z;
+    p.tan_half_fov = ( float ) tan ( ( double ) ( ( cam->fov * 0.0174533f ) / 2 ) );     // double tan of a float argument, src/Terra.c:1794
+    p.aspect = ( float ) fb_w / ( float ) fb_h;
+    p.jitter = s->opts.subpixel_jitter; p.exposure = s->opts.manual_exposure; p.gamma = s->opts.gamma;
+    p.fb_w = ( uint32_t ) fb_w; p.fb_h = ( uint32_t ) fb_h;
+    p.x = ( uint32_t ) x; p.y = ( uint32_t ) y; p.w = ( uint32_t ) w; p.h = ( uint32_t ) h;
+    p.tile_size = ( uint32_t ) tile; p.rank = ( uint32_t ) rank; p.world = ( uint32_t ) world;
+    p.spp = effective_spp ( s->opts );
+    p.bounces = ( uint32_t ) s->opts.bounces;
+    p.integrator = ( int32_t ) s->opts.integrator; p.tonemap = ( int32_t ) s->opts.tonemapping_operator;
+    if ( p.integrator < 0 || p.integrator > 6 ) return fail ( kTerraAmdErrBadArgument, "unknown integrator %d", p.integrator );
+    if ( ( p.integrator == kTerraIntegratorDirect || p.integrator == kTerraIntegratorDirectMis || p.integrator == kTerraIntegratorDebugMisWeights ) && s->lights.empty() )
+        return fail ( kTerraAmdErrBadArgument, "integrator %d needs at least one emissive object (the reference asserts, src/Terra.c:1617)", p.integrator );
+    p.frame_seed = s->frame_seed;
+    p.counters = s->d_counters;
+    return 0;
+}
+
+extern "C" int terra_amd_render_device_sharded ( const TerraCamera* cam, HTerraScene h, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h,
+                                                 size_t x, size_t y, size_t w, size_t hgt, size_t tile, int rank, int world, void* d_rand_calls, void* stream ) {
+    Scene* s = S ( h );
+    DevRenderParams p;
+    int rc = fill_params ( s, cam, fb_w, fb_h, x, y, w, hgt, tile, rank, world, p );
+    if ( rc ) return rc;
+    if ( !d_pixels || !d_results ) return fail ( kTerraAmdErrBadArgument, "null framebuffer pointer" );
+    p.pixels = ( float* ) d_pixels; p.results = d_results; p.rand_calls = ( uint32_t* ) d_rand_calls;
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
+    HIP_TRY ( terra_launch_render ( p, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
+    ++s->launches;
+    return 0;
+}
+extern "C" int terra_amd_render_device ( const TerraCamera* cam, HTerraScene h, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h,
+                                         size_t x, size_t y, size_t w, size_t hgt, void* d_rand_calls, void* stream ) {
+    return terra_amd_render_device_sharded ( cam, h, d_pixels, d_results, fb_w, fb_h, x, y, w, hgt, 64, 0, 1, d_rand_calls, stream );
+}
+extern "C" int terra_amd_synchronize ( void* stream ) {
+    HIP_TRY ( hipStreamSynchronize ( ( hipStream_t ) stream ), kTerraAmdErrLaunch );
+    return 0;
+}
+extern "C" int terra_amd_time_render_device ( const TerraCamera* cam, HTerraScene h, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h,
+                                              size_t x, size_t y, size_t w, size_t hgt, int launches, void* stream, float* ms_avg ) {
+    if ( launches < 1 || !ms_avg ) return fail ( kTerraAmdErrBadArgument, "launches < 1" );
+    hipEvent_t e0, e1;
+    HIP_TRY ( hipSetDevice ( S ( h )->device ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipEventCreate ( &e0 ), kTerraAmdErrLaunch ); HIP_TRY ( hipEventCreate ( &e1 ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipEventRecord ( e0, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
+    for ( int i = 0; i < launches; ++i ) {
+        int rc = terra_amd_render_device ( cam, h, d_pixels, d_results, fb_w, fb_h, x, y, w, hgt, nullptr, stream );
+        if ( rc ) { ( void ) hipEventDestroy ( e0 ); ( void ) hipEventDestroy ( e1 ); return rc; }
+    }
+    HIP_TRY ( hipEventRecord ( e1, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipEventSynchronize ( e1 ), kTerraAmdErrLaunch );
+    float ms = 0.f;
+    HIP_TRY ( hipEventElapsedTime ( &ms, e0, e1 ), kTerraAmdErrLaunch );
+    ( void ) hipEventDestroy ( e0 ); ( void ) hipEventDestroy ( e1 );
+    *ms_avg = ms / ( float ) launches;
+    return 0;
+}
+
+// ---- tile pack/unpack ------------------------------------------------------------
+static uint32_t tiles_of_rank ( size_t w, size_t h, size_t tile, int rank, int world ) {
+    size_t tiles = ( ( w + tile - 1 ) / tile ) * ( ( h + tile - 1 ) / tile );
+    return tiles > ( size_t ) rank ? ( uint32_t ) ( ( tiles - ( size_t ) rank + ( size_t ) world - 1 ) / ( size_t ) world ) : 0u;
+}
+extern "C" int terra_amd_shard_tile_count ( size_t w, size_t h, size_t tile, int rank, int world ) {
+    if ( tile == 0 || world < 1 || rank < 0 || rank >= world ) return fail ( kTerraAmdErrBadArgument, "bad shard arguments" );
+    return ( int ) tiles_of_rank ( w, h, tile, rank, world );
+}
+extern "C" size_t terra_amd_shard_packed_bytes ( size_t w, size_t h, size_t tile, int world ) {
+    if ( tile == 0 || world < 1 ) return 0;
+    return ( size_t ) tiles_of_rank ( w, h, tile, 0, world ) * tile * tile * 28;     // rank 0 holds the most tiles
+}
+static int tiles_call ( bool pack, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h, size_t x, size_t y, size_t w, size_t h, size_t tile, int rank, int world, void* d_packed, void* stream ) {
+    if ( !d_pixels || !d_results || !d_packed || tile == 0 || tile % 16 != 0 || world < 1 || rank < 0 || rank >= world || x + w > fb_w || y + h > fb_h )
+        return fail ( kTerraAmdErrBadArgument, "bad pack/unpack arguments" );
+    HIP_TRY ( terra_launch_tiles ( pack, ( float* ) d_pixels, d_results, ( uint32_t ) fb_w, ( uint32_t ) x, ( uint32_t ) y, ( uint32_t ) w, ( uint32_t ) h,
+                                   ( uint32_t ) tile, ( uint32_t ) rank, ( uint32_t ) world, ( float* ) d_packed, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
+    return ( int ) tiles_of_rank ( w, h, tile, rank, world );
+}
+extern "C" int terra_amd_pack_tiles ( const void* d_pixels, const void* d_results, size_t fb_w, size_t fb_h, size_t x, size_t y, size_t w, size_t h, size_t tile, int rank, int world, void* d_packed, void* stream ) {
+    return tiles_call ( true, ( void* ) d_pixels, ( void* ) d_results, fb_w, fb_h, x, y, w, h, tile, rank, world, d_packed, stream );
+}
+extern "C" int terra_amd_unpack_tiles ( void* d_pixels, void* d_results, size_t fb_w, size_t fb_h, size_t x, size_t y, size_t w, size_t h, size_t tile, int rank, int world, const void* d_packed, void* stream ) {
+    return tiles_call ( false, d_pixels, d_results, fb_w, fb_h, x, y, w, h, tile, rank, world, ( void* ) d_packed, stream );
+}
+
+// ---- terra_render on a HOST framebuffer (the drop-in entry point) -------------------
+// Per calling thread: one stream and a device staging framebuffer the size of the
+// largest framebuffer seen. The tile's running sums go up (they key the random
+// streams and are accumulated on), the kernel renders, the tile comes back.
+struct ThreadSlot { int device = -1; hipStream_t stream = nullptr; void* d_pixels = nullptr; void* d_results = nullptr; size_t cap_px = 0; };
+static thread_local ThreadSlot t_slot;
+
+static int slot_prepare ( int device, size_t npx ) {
+    ThreadSlot& t = t_slot;
+    HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );
+    if ( t.device != device ) {
+        if ( t.stream ) { ( void ) hipStreamDestroy ( t.stream ); ( void ) hipFree ( t.d_pixels ); ( void ) hipFree ( t.d_results ); }
+        t = ThreadSlot(); t.device = device;
+        HIP_TRY ( hipStreamCreateWithFlags ( &t.stream, hipStreamNonBlocking ), kTerraAmdErrNoDevice );
+    }
+    if ( t.cap_px < npx ) {
+        if ( t.d_pixels ) ( void ) hipFree ( t.d_pixels );
+        if ( t.d_results ) ( void ) hipFree ( t.d_results );
+        t.d_pixels = t.d_results = nullptr; t.cap_px = 0;
+        HIP_TRY ( hipMalloc ( &t.d_pixels, npx * 12 ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMalloc ( &t.d_results, npx * 16 ), kTerraAmdErrNoDevice );
+        t.cap_px = npx;
+    }
+    return 0;
+}
+
+static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t h ) {
+    if ( !fb || !fb->pixels || !fb->results ) return fail ( kTerraAmdErrBadArgument, "null framebuffer" );
+    DevRenderParams p;
+    int rc = fill_params ( s, cam, fb->width, fb->height, x, y, w, h, 64, 0, 1, p );
+    if ( rc ) return rc;
+    rc = slot_prepare ( s->device, fb->width * fb->height );
+    if ( rc ) return rc;
+    ThreadSlot& t = t_slot;
+    // staging uses the framebuffer's own indexing, so the kernel is the same as for device-resident frames
+    const size_t rpitch = fb->width * 16, ppitch = fb->width * 12;
+    char* dres = ( char* ) t.d_results + ( y * fb->width + x ) * 16;
+    char* dpix = ( char* ) t.d_pixels + ( y * fb->width + x ) * 12;
+    const char* hres = ( const char* ) fb->results + ( y * fb->width + x ) * 16;
+    char* hpix = ( char* ) fb->pixels + ( y * fb->width + x ) * 12;
+    HIP_TRY ( hipMemcpy2DAsync ( dres, rpitch, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, t.stream ), kTerraAmdErrLaunch );
+    p.pixels = ( float* ) t.d_pixels; p.results = t.d_results; p.rand_calls = nullptr;
+    HIP_TRY ( terra_launch_render ( p, t.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, dres, rpitch, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, dpix, ppitch, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipStreamSynchronize ( t.stream ), kTerraAmdErrLaunch );
+    ++s->launches;
+    return 0;
+}
+
+extern "C" void terra_render ( const TerraCamera* cam, HTerraScene h, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t hgt ) {
+    ( void ) render_host ( cam, S ( h ), fb, x, y, w, hgt );      // failures are recorded in terra_amd_last_error()
+}
+
+// ------------------------------------------------------------------------------
+// unit-level entry points: host arrays in, device function, host arrays out
+// ------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0; void* host = nullptr; bool out = false;
+    ~DevBuf() { if ( p ) ( void ) hipFree ( p ); }
+};
+struct Unit {
+    std::vector<DevBuf*> bufs; bool ok = true;
+    ~Unit() { for ( DevBuf* b : bufs ) delete b; }
+    template <class T> T* in ( const T* host, size_t count ) { return ( T* ) make ( ( void* ) host, count * sizeof ( T ), true, false ); }
+    template <class T> T* out ( T* host, size_t count ) { return ( T* ) make ( host, count * sizeof ( T ), false, true ); }
+    template <class T> T* inout ( T* host, size_t count ) { return ( T* ) make ( host, count * sizeof ( T ), true, true ); }
+    void* make ( void* host, size_t bytes, bool copy_in, bool copy_out ) {
+        DevBuf* b = new DevBuf(); bufs.push_back ( b );
+        b->bytes = bytes; b->host = host; b->out = copy_out;
+        if ( hipMalloc ( &b->p, bytes ? bytes : 4 ) != hipSuccess ) { ok = false; return nullptr; }
+        if ( copy_in && bytes && hipMemcpy ( b->p, host, bytes, hipMemcpyHostToDevice ) != hipSuccess ) ok = false;
+        if ( !copy_in && bytes && hipMemset ( b->p, 0, bytes ) != hipSuccess ) ok = false;
+        return b->p;
+    }
+    int finish ( hipError_t launch ) {
+        if ( !ok ) return fail ( kTerraAmdErrNoDevice, "unit call: device allocation/copy failed" );
+        if ( launch != hipSuccess ) return fail ( kTerraAmdErrLaunch, "unit kernel launch: %s", hipGetErrorString ( launch ) );
+        hipError_t e = hipDeviceSynchronize();
+        if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "unit kernel: %s", hipGetErrorString ( e ) );
+        for ( DevBuf* b : bufs ) if ( b->out && b->bytes && hipMemcpy ( b->host, b->p, b->bytes, hipMemcpyDeviceToHost ) != hipSuccess ) return fail ( kTerraAmdErrLaunch, "unit copy back failed" );
+        return 0;
+    }
+};
+int need_device() { return terra_amd_device_count() > 0 ? 0 : fail ( kTerraAmdErrNoDevice, "no HIP device visible" ); }
+int need_scene ( Scene* s ) {
+    if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "scene not committed" );
+    if ( !s->device_ok ) return fail ( kTerraAmdErrNoDevice, "scene has no device replica: %s", s->commit_error.c_str() );
+    ( void ) hipSetDevice ( s->device );
+    return 0;
+}
+}
+
+extern "C" int terra_amd_unit_pcg ( const uint32_t* seeds, int nseeds, int n, float* out ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto ds = u.in ( seeds, nseeds ); auto dout = u.out ( out, ( size_t ) nseeds * n );
+    return u.finish ( u.ok ? terra_unit_pcg ( ds, nseeds, n, dout ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_stream_keys ( uint64_t seed, const uint64_t* pix, const uint64_t* k, int n, uint64_t* out3 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto a = u.in ( pix, n ); auto b = u.in ( k, n ); auto o = u.out ( out3, ( size_t ) 3 * n );
+    return u.finish ( u.ok ? terra_unit_stream_keys ( seed, a, b, n, o ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_ray_aabb ( int n, const float* o, const float* d, const float* boxes, int* hit, float* tmin, float* tmax ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n ); auto c = u.in ( boxes, 6 * ( size_t ) n );
+    auto h = u.out ( hit, n ); auto t0 = u.out ( tmin, n ); auto t1 = u.out ( tmax, n );
+    return u.finish ( u.ok ? terra_unit_ray_aabb ( n, a, b, c, h, t0, t1 ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_watertight ( int n, const float* o, const float* d, const float* tris, int* hit, float* out8 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n ); auto c = u.in ( tris, 9 * ( size_t ) n );
+    auto h = u.out ( hit, n ); auto q = u.out ( out8, 8 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_watertight ( n, a, b, c, h, q ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_moller_trumbore ( int n, const float* o, const float* d, const float* tris, int* hit, float* out4 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n ); auto c = u.in ( tris, 9 * ( size_t ) n );
+    auto h = u.out ( hit, n ); auto q = u.out ( out4, 4 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_moller_trumbore ( n, a, b, c, h, q ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_bvh_traverse ( HTerraScene hs, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point3 ) {
+    Scene* s = S ( hs ); int rc = need_scene ( s ); if ( rc ) return rc;
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n );
+    auto f = u.out ( found, n ); auto pr = u.out ( prim, n ); auto pt = u.out ( point3, 3 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_bvh_traverse ( s->dev, n, a, b, f, pr, pt ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_raycast ( HTerraScene hs, int n, const float* o, const float* d, int* obj, int* tri, float* point3, float* surface47 ) {
+    Scene* s = S ( hs ); int rc = need_scene ( s ); if ( rc ) return rc;
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n );
+    auto ob = u.out ( obj, n ); auto tr = u.out ( tri, n ); auto pt = u.out ( point3, 3 * ( size_t ) n ); auto sf = u.out ( surface47, 47 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_raycast ( s->dev, n, a, b, ob, tr, pt, sf ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_trace ( HTerraScene hs, int n, const float* o, const float* d, const uint64_t* stateB, const uint64_t* incB, float* radiance3, uint32_t* rand_calls ) {
+    Scene* s = S ( hs ); int rc = need_scene ( s ); if ( rc ) return rc;
+    if ( ( s->opts.integrator == kTerraIntegratorDirect || s->opts.integrator == kTerraIntegratorDirectMis || s->opts.integrator == kTerraIntegratorDebugMisWeights ) && s->lights.empty() )
+        return fail ( kTerraAmdErrBadArgument, "integrator needs a light" );
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n ); auto sb = u.in ( stateB, n ); auto ib = u.in ( incB, n );
+    auto L = u.out ( radiance3, 3 * ( size_t ) n ); auto rcalls = u.out ( rand_calls, n );
+    return u.finish ( u.ok ? terra_unit_trace ( s->dev, ( int ) s->opts.integrator, ( uint32_t ) s->opts.bounces, n, a, b, sb, ib, L, rcalls ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    if ( kind != kDevBsdfDiffuse && kind != kDevBsdfPhong ) return fail ( kTerraAmdErrBadArgument, "unknown bsdf kind %d", kind );
+    Unit u; auto sf = u.inout ( surfaces47, 47 * ( size_t ) n ); auto e = u.in ( e3, 3 * ( size_t ) n ); auto wo = u.in ( wo3, 3 * ( size_t ) n );
+    auto wi = u.out ( wi3, 3 * ( size_t ) n ); auto pd = u.out ( pdf, n ); auto f = u.out ( f3, 3 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_bsdf ( kind, n, sf, e, wo, wi, pd, f ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_camera ( const TerraCamera* cam, size_t fb_w, size_t fb_h, int n, const uint32_t* xy2, float jitter, const float* r2, float* dirs3 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    DevRenderParams p; memset ( &p, 0, sizeof p );
+    TerraFloat3 z = terra_normf3 ( &cam->direction );
+    TerraFloat3 xa = terra_crossf3 ( &cam->up, &z ); xa = terra_normf3 ( &xa );
+    TerraFloat3 ya = terra_crossf3 ( &z, &xa );
+    p.cam_rot[0] = xa.x; p.cam_rot[1] = ya.x; p.cam_rot[2] = z.x; p.cam_rot[3] = xa.y; p.cam_rot[4] = ya.y; p.cam_rot[5] = z.y; p.cam_rot[6] = xa.z; p.cam_rot[7] = ya.z; p.cam_rot[8] = z.z;
+    p.tan_half_fov = ( float ) tan ( ( double ) ( ( cam->fov * 0.0174533f ) / 2 ) );
+    p.aspect = ( float ) fb_w / ( float ) fb_h; p.jitter = jitter; p.fb_w = ( uint32_t ) fb_w; p.fb_h = ( uint32_t ) fb_h;
+    Unit u; auto a = u.in ( xy2, 2 * ( size_t ) n ); auto b = u.in ( r2, 2 * ( size_t ) n ); auto o = u.out ( dirs3, 3 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_camera ( p, n, a, b, o ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_tonemap ( int op, float gamma, int n, float* colors3 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto c = u.inout ( colors3, 3 * ( size_t ) n );
+    return u.finish ( u.ok ? terra_unit_tonemap ( op, gamma, n, c ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_math ( int fn, int n, const float* x, const float* y, float* out ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    Unit u; auto a = u.in ( x, n ); auto b = u.in ( y ? y : x, n ); auto o = u.out ( out, n );
+    return u.finish ( u.ok ? terra_unit_math ( fn, n, a, b, o ) : hipSuccess );
+}

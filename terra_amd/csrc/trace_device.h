@@ -1,0 +1,581 @@
+// trace_device.h -- device functions of the hot path (gfx950).
+//
+//   camera sample            reference src/Terra.c:1783-1799
+//   slab test                reference src/Terra.c:851-878
+//   watertight ray/triangle  reference src/TerraGeometry.c:98-138, 159-260
+//   Moeller-Trumbore         reference src/Terra.c:880-922 (unit level only)
+//   BVH stack traversal      reference src/TerraBVH.c:250-310
+//   raycast + surface init   reference src/Terra.c:1623-1657, 1726-1764, TerraMath.inl:251-272
+//   diffuse / Phong presets  reference src/TerraPresets.c:34-146
+//   integrators              reference src/Terra.c:1099-1587
+//   bounce loop              reference src/Terra.c:1039-1097
+//   tonemap                  reference src/Terra.c:578-627, 1815-1828
+//
+// Arithmetic rules (DESIGN.md "Bit-faithful arithmetic"): binary32 everywhere the
+// reference is binary32, the reference's double promotions kept, operation order
+// kept, no FMA contraction (-ffp-contract=off), IEEE division and square root,
+// compare-select min/max where a NaN could reach them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "dev_types.h"
+#include "dev_math.h"
+#include "rng.h"
+
+#define TD __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+
+TD V3 v3 ( float x, float y, float z ) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+TD V3 v3p ( const float* p ) { return v3 ( p[0], p[1], p[2] ); }
+TD V3 operator+ ( V3 a, V3 b ) { return v3 ( a.x + b.x, a.y + b.y, a.z + b.z ); }
+TD V3 operator- ( V3 a, V3 b ) { return v3 ( a.x - b.x, a.y - b.y, a.z - b.z ); }
+TD V3 operator* ( V3 a, float s ) { return v3 ( a.x * s, a.y * s, a.z * s ); }
+TD V3 had ( V3 a, V3 b ) { return v3 ( a.x * b.x, a.y * b.y, a.z * b.z ); }
+TD V3 neg ( V3 a ) { return v3 ( -a.x, -a.y, -a.z ); }
+TD float dot ( V3 a, V3 b ) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+TD V3 cross ( V3 a, V3 b ) { return v3 ( a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x ); }
+TD float length ( V3 a ) { return sqrtf ( a.x * a.x + a.y * a.y + a.z * a.z ); }
+TD V3 normalize ( V3 a ) { float l = length ( a ); return v3 ( a.x / l, a.y / l, a.z / l ); }
+// compare-selects: exactly "a < b ? a : b" / "a > b ? a : b" (NaN-order sensitive)
+TD float sel_min ( float a, float b ) { return a < b ? a : b; }
+TD float sel_max ( float a, float b ) { return a > b ? a : b; }
+TD float pick ( V3 a, int i ) { return i == 0 ? a.x : ( i == 1 ? a.y : a.z ); }
+
+// columns of the shading basis: tangent, normal, bitangent. Stored by rows as the reference does.
+struct Basis { float r0[3], r1[3], r2[3]; };
+TD V3 basis_apply ( const Basis& m, V3 v ) {
+    return v3 ( m.r0[0] * v.x + m.r0[1] * v.y + m.r0[2] * v.z,
+                m.r1[0] * v.x + m.r1[1] * v.y + m.r1[2] * v.z,
+                m.r2[0] * v.x + m.r2[1] * v.y + m.r2[2] * v.z );
+}
+TD Basis make_basis ( V3 n ) {
+    V3 t;
+    if ( fabsf ( n.x ) > fabsf ( n.y ) ) {
+        float k = sqrtf ( n.x * n.x + n.z * n.z );
+        t = v3 ( n.z * k, 0.f * k, -n.x * k );
+    } else {
+        float k = sqrtf ( n.y * n.y + n.z * n.z );
+        t = v3 ( 0.f * k, -n.z * k, n.y * k );
+    }
+    V3 b = cross ( n, t );
+    Basis m;
+    m.r0[0] = t.x; m.r0[1] = n.x; m.r0[2] = b.x;
+    m.r1[0] = t.y; m.r1[1] = n.y; m.r1[2] = b.y;
+    m.r2[0] = t.z; m.r2[1] = n.z; m.r2[2] = b.z;
+    return m;
+}
+
+struct Ray { V3 o, d, inv; };
+TD Ray make_ray ( V3 o, V3 d ) { Ray r; r.o = o; r.d = d; r.inv = v3 ( 1.f / d.x, 1.f / d.y, 1.f / d.z ); return r; }
+
+struct RayState { float shearx, sheary, scalez; int ix, iy, iz; };
+
+// per-lane work counters (registers); flushed with one atomic per wave and counter
+struct Counters { uint32_t rays, nodes, box_tests, tri_tests, hits, samples, rand_calls, attr_fetches; };
+TD Counters counters_zero() { Counters c; c.rays = c.nodes = c.box_tests = c.tri_tests = c.hits = c.samples = c.rand_calls = c.attr_fetches = 0; return c; }
+
+// -----------------------------------------------------------------------------
+// camera
+// -----------------------------------------------------------------------------
+TD V3 camera_sample ( const DevRenderParams& p, uint32_t px, uint32_t py, float r1, float r2 ) {
+    float dx = -p.jitter + 2 * r1 * p.jitter;
+    float dy = -p.jitter + 2 * r2 * p.jitter;
+    float ndc_x = ( ( float ) px + 0.5f + dx ) / ( float ) p.fb_w;
+    float ndc_y = ( ( float ) py + 0.5f + dy ) / ( float ) p.fb_h;
+    float sx = 2 * ndc_x - 1;
+    float sy = 1 - 2 * ndc_y;
+    float fx = sx * p.aspect * p.tan_half_fov;
+    float fy = sy * p.tan_half_fov;
+    V3 d = normalize ( v3 ( fx, fy, 1.f ) );
+    return v3 ( p.cam_rot[0] * d.x + p.cam_rot[1] * d.y + p.cam_rot[2] * d.z,
+                p.cam_rot[3] * d.x + p.cam_rot[4] * d.y + p.cam_rot[5] * d.z,
+                p.cam_rot[6] * d.x + p.cam_rot[7] * d.y + p.cam_rot[8] * d.z );
+}
+
+// -----------------------------------------------------------------------------
+// slab test
+// -----------------------------------------------------------------------------
+TD bool ray_aabb ( const Ray& r, V3 bmin, V3 bmax, float* tmin_out, float* tmax_out ) {
+    float t1 = ( bmin.x - r.o.x ) * r.inv.x;
+    float t2 = ( bmax.x - r.o.x ) * r.inv.x;
+    float tmin = sel_min ( t1, t2 ), tmax = sel_max ( t1, t2 );
+    t1 = ( bmin.y - r.o.y ) * r.inv.y;
+    t2 = ( bmax.y - r.o.y ) * r.inv.y;
+    tmin = sel_max ( tmin, sel_min ( t1, t2 ) ); tmax = sel_min ( tmax, sel_max ( t1, t2 ) );
+    t1 = ( bmin.z - r.o.z ) * r.inv.z;
+    t2 = ( bmax.z - r.o.z ) * r.inv.z;
+    tmin = sel_max ( tmin, sel_min ( t1, t2 ) ); tmax = sel_min ( tmax, sel_max ( t1, t2 ) );
+    bool hit = tmax > sel_max ( tmin, 0.f );
+    if ( tmin_out ) *tmin_out = tmin;
+    if ( tmax_out ) *tmax_out = tmax;
+    return hit;
+}
+
+// -----------------------------------------------------------------------------
+// watertight ray/triangle
+// -----------------------------------------------------------------------------
+TD RayState ray_state_init ( const Ray& r ) {
+    float ax = fabsf ( r.d.x ), ay = fabsf ( r.d.y ), az = fabsf ( r.d.z );
+    int iz = ax > ay ? ( ax > az ? 0 : 2 ) : ( ay > az ? 1 : 2 );   // ties -> later axis
+    int ix = iz + 1 == 3 ? 0 : iz + 1;
+    int iy = ix + 1 == 3 ? 0 : ix + 1;
+    if ( pick ( r.d, iz ) < 0.f ) { int t = ix; ix = iy; iy = t; }
+    RayState s;
+    s.scalez = 1.f / pick ( r.d, iz );
+    s.shearx = pick ( r.d, ix ) * s.scalez;
+    s.sheary = pick ( r.d, iy ) * s.scalez;
+    s.ix = ix; s.iy = iy; s.iz = iz;
+    return s;
+}
+
+struct TriHit { float u, v, w, depth; V3 point; };
+
+TD bool watertight ( const Ray& r, const RayState& s, V3 ta, V3 tb, V3 tc, TriHit& h ) {
+    V3 A = ta - r.o, B = tb - r.o, C = tc - r.o;
+    float Aiz = pick ( A, s.iz ), Biz = pick ( B, s.iz ), Ciz = pick ( C, s.iz );
+    float Ax = pick ( A, s.ix ) - s.shearx * Aiz, Ay = pick ( A, s.iy ) - s.sheary * Aiz;
+    float Bx = pick ( B, s.ix ) - s.shearx * Biz, By = pick ( B, s.iy ) - s.sheary * Biz;
+    float Cx = pick ( C, s.ix ) - s.shearx * Ciz, Cy = pick ( C, s.iy ) - s.sheary * Ciz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if ( U == 0.f || V == 0.f || W == 0.f ) {
+        U = ( float ) ( ( double ) Cx * ( double ) By - ( double ) Cy * ( double ) Bx );
+        V = ( float ) ( ( double ) Ax * ( double ) Cy - ( double ) Ay * ( double ) Cx );
+        W = ( float ) ( ( double ) Bx * ( double ) Ay - ( double ) By * ( double ) Ax );
+    }
+    uint32_t sign = tdm_bits ( U ) & 0x80000000u;
+    if ( ( ( tdm_bits ( V ) ^ tdm_bits ( U ) ) | ( tdm_bits ( W ) ^ tdm_bits ( U ) ) ) & 0x80000000u ) return false;
+    float det = U + V + W;
+    if ( det == 0.f ) return false;
+    float Az = s.scalez * Aiz, Bz = s.scalez * Biz, Cz = s.scalez * Ciz;
+    float depth = U * Az + V * Bz + W * Cz;
+    if ( tdm_float ( tdm_bits ( depth ) ^ sign ) < 0.f ) return false;
+    float inv_det = 1.f / det;
+    h.u = U * inv_det; h.v = V * inv_det; h.w = W * inv_det;
+    h.depth = depth * inv_det;
+    h.point = r.o + r.d * h.depth;
+    return true;
+}
+
+TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_out ) {
+    V3 e1 = tb - ta, e2 = tc - ta;
+    V3 h = cross ( d, e2 );
+    float a = dot ( e1, h );
+    if ( ( double ) a > -1e-4 && ( double ) a < 1e-4 ) return false;
+    float f = 1 / a;
+    V3 s = o - ta;
+    float u = f * dot ( s, h );
+    if ( u < 0.f || u > 1.f ) return false;
+    V3 q = cross ( s, e1 );
+    float v = f * dot ( d, q );
+    if ( v < 0.f || u + v > 1.f ) return false;
+    float t = f * dot ( e2, q );
+    if ( t > 0.00001f ) { t_out = t; p_out = d * t + o; return true; }
+    return false;
+}
+
+// -----------------------------------------------------------------------------
+// BVH traversal. `stack` points at this lane's column of the LDS stack,
+// consecutive entries are `stride` ints apart (bank-conflict-free per wave).
+// Order of events per popped node matches the reference: child 0 before child 1
+// both for pushes and for leaf tests; a leaf replaces the closest hit only if
+// strictly closer, so ties keep the earlier leaf.
+// -----------------------------------------------------------------------------
+struct Closest { float depth; V3 point; uint32_t tri; uint32_t prim; bool found; };
+
+template <bool COUNT>
+TD Closest bvh_traverse ( const DevScene& sc, const Ray& r, const RayState& st, int* stack, int stride, Counters& c ) {
+    Closest best; best.depth = FLT_MAX; best.point = v3 ( FLT_MAX, FLT_MAX, FLT_MAX ); best.tri = 0; best.prim = 0; best.found = false;
+    int top = 1;
+    stack[0] = 0;
+    const float4* nodes = reinterpret_cast<const float4*> ( sc.nodes );
+    const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
+    while ( top > 0 ) {
+        int ni = stack[ ( --top ) * stride];
+        float4 q0 = nodes[4 * ni + 0], q1 = nodes[4 * ni + 1], q2 = nodes[4 * ni + 2], q3 = nodes[4 * ni + 3];
+        uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+        if ( COUNT ) ++c.nodes;
+        bool inner0 = ( child0 & DEV_CHILD_LEAF ) == 0, inner1 = ( child1 & DEV_CHILD_LEAF ) == 0;
+        if ( inner0 ) {
+            if ( COUNT ) ++c.box_tests;
+            if ( ray_aabb ( r, v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), nullptr, nullptr ) ) { stack[top * stride] = ( int ) child0; ++top; }
+        }
+        if ( inner1 ) {
+            if ( COUNT ) ++c.box_tests;
+            if ( ray_aabb ( r, v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), nullptr, nullptr ) ) { stack[top * stride] = ( int ) child1; ++top; }
+        }
+        #pragma unroll
+        for ( int i = 0; i < 2; ++i ) {
+            uint32_t ch = i == 0 ? child0 : child1;
+            if ( ( ch & DEV_CHILD_LEAF ) && ch != DEV_CHILD_EMPTY ) {
+                uint32_t ti = ch & 0x7fffffffu;
+                float4 a = tris[3 * ti + 0], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
+                if ( COUNT ) ++c.tri_tests;
+                TriHit h;
+                if ( watertight ( r, st, v3 ( a.x, a.y, a.z ), v3 ( b.x, b.y, b.z ), v3 ( cc.x, cc.y, cc.z ), h ) && h.depth < best.depth ) {
+                    best.depth = h.depth; best.point = h.point; best.tri = ti;
+                    best.prim = __float_as_uint ( i == 0 ? q3.z : q3.w );
+                    best.found = true;
+                }
+            }
+        }
+    }
+    return best;
+}
+
+// -----------------------------------------------------------------------------
+// surface
+// -----------------------------------------------------------------------------
+struct Surface {
+    V3    normal;
+    V3    emissive;
+    V3    attr[4];      // the presets use at most 4 slots (Phong); slot 3.x is Phong's sample-pick scratch
+    Basis basis;
+    int   bsdf;
+};
+
+TD void surface_init ( const DevScene& sc, uint32_t ti, V3 point, Surface& sf, uint32_t& object_out, uint32_t& tri_in_object_out, uint32_t& nattr_out ) {
+    const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
+    const float4* props = reinterpret_cast<const float4*> ( sc.props );
+    float4 t0 = tris[3 * ti + 0], t1 = tris[3 * ti + 1], t2 = tris[3 * ti + 2];
+    V3 ta = v3 ( t0.x, t0.y, t0.z ), tb = v3 ( t1.x, t1.y, t1.z ), tc = v3 ( t2.x, t2.y, t2.z );
+    uint32_t object = __float_as_uint ( t0.w );
+    object_out = object; tri_in_object_out = __float_as_uint ( t1.w );
+    V3 e0 = tb - ta, e1 = tc - ta, p = point - ta;
+    float d00 = dot ( e0, e0 ), d11 = dot ( e1, e1 ), d01 = dot ( e0, e1 );
+    float dp0 = dot ( p, e0 ), dp1 = dot ( p, e1 );
+    float div = d00 * d11 - d01 * d01;
+    float u = ( d11 * dp0 - d01 * dp1 ) / div;
+    float v = ( d00 * dp1 - d01 * dp0 ) / div;
+    float w = 1 - u - v;
+    float4 p0 = props[4 * ti + 0], p1 = props[4 * ti + 1], p2 = props[4 * ti + 2];
+    V3 na = v3 ( p0.x, p0.y, p0.z ), nb = v3 ( p0.w, p1.x, p1.y ), nc = v3 ( p1.z, p1.w, p2.x );
+    sf.normal = normalize ( ( nc * v + nb * u ) + na * w );
+    // texcoords are only consumed by textured attributes (not on the device yet): constants ignore them
+    const DevMaterial& m = sc.mats[object];
+    sf.emissive = v3p ( m.emissive );
+    #pragma unroll
+    for ( int i = 0; i < 4; ++i ) sf.attr[i] = v3p ( m.attributes[i] );
+    sf.bsdf = m.bsdf;
+    nattr_out = m.attributes_count;
+    sf.basis = make_basis ( sf.normal );
+}
+
+struct RaycastResult { bool hit; uint32_t object, tri_in_object, tri; V3 point; };
+
+template <bool COUNT>
+TD RaycastResult scene_raycast ( const DevScene& sc, const Ray& in, Surface& sf, int* stack, int stride, Counters& c ) {
+    Ray r = in;
+    r.o = r.o + r.d * 0.001f;
+    RayState st = ray_state_init ( r );
+    if ( COUNT ) ++c.rays;
+    Closest best = bvh_traverse<COUNT> ( sc, r, st, stack, stride, c );
+    RaycastResult res; res.hit = best.found; res.point = best.point; res.tri = best.tri; res.object = 0; res.tri_in_object = 0;
+    if ( best.found ) {
+        uint32_t nattr;
+        surface_init ( sc, best.tri, best.point, sf, res.object, res.tri_in_object, nattr );
+        if ( COUNT ) { ++c.hits; c.attr_fetches += nattr + 1; }
+    }
+    return res;
+}
+
+TD Ray surface_ray ( const Surface& sf, V3 p, V3 d, float sign ) {
+    V3 off = sf.normal * ( 0.0001f * sign );
+    return make_ray ( p + off, d );
+}
+
+// -----------------------------------------------------------------------------
+// BSDF presets
+// -----------------------------------------------------------------------------
+#define TERRA_PI_F 3.1416926535f
+
+TD V3 diffuse_sample ( const Surface& sf, float e1, float e2 ) {
+    float r = sqrtf ( e1 );
+    float theta = 2 * TERRA_PI_F * e2;
+    float x = r * tdm_cosf ( theta );
+    float z = r * tdm_sinf ( theta );
+    V3 wi = v3 ( x, sqrtf ( sel_max ( 0.f, 1 - e1 ) ), z );
+    return normalize ( basis_apply ( sf.basis, wi ) );
+}
+TD float diffuse_pdf ( const Surface& sf, V3 wi ) { return sel_max ( 0.f, dot ( sf.normal, wi ) ) / TERRA_PI_F; }
+TD V3 diffuse_eval ( const Surface& sf ) { return sf.attr[0] * ( float ) ( 1. / ( double ) TERRA_PI_F ); }
+
+TD void phong_kd_ks ( const Surface& sf, float& kd, float& ks ) {
+    V3 al = sf.attr[1], sp = sf.attr[0];
+    float diffuse = sel_max ( al.x + al.y + al.z, ( float ) 1e-4 );
+    float specular = sp.x + sp.y + sp.z;
+    if ( specular > diffuse ) { kd = 0.5f * diffuse / specular; ks = 1.f - kd; }
+    else { ks = 0.5f * specular / diffuse; kd = 1.f - ks; }
+}
+TD V3 phong_reflect ( const Surface& sf, V3 wo ) { return sf.normal * ( 2.f * dot ( wo, sf.normal ) ) - wo; }
+
+TD V3 phong_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
+    float kd, ks; phong_kd_ks ( sf, kd, ks );
+    if ( e3 < kd ) { sf.attr[3].x = 1.f; return diffuse_sample ( sf, e1, e2 ); }
+    sf.attr[3].x = -1.f;
+    V3 wr = phong_reflect ( sf, wo );
+    Basis b = make_basis ( wr );
+    float phi = 2 * TERRA_PI_F * e1;
+    float theta = tdm_acosf ( tdm_powf ( 1.f - e2, 1.f / ( sf.attr[2].x + 1 ) ) );
+    float sin_theta = tdm_sinf ( theta );
+    V3 wi = v3 ( sin_theta * tdm_cosf ( phi ), tdm_cosf ( theta ), sin_theta * tdm_sinf ( phi ) );
+    return normalize ( basis_apply ( b, wi ) );
+}
+TD float phong_pdf ( const Surface& sf, V3 wi, V3 wo ) {
+    if ( sf.attr[3].x == 1.f ) return diffuse_pdf ( sf, wi );
+    V3 wr = phong_reflect ( sf, wo );
+    float cos_alpha = dot ( wi, wr );
+    float n = sf.attr[2].x;
+    return ( n + 1 ) / ( 2 * TERRA_PI_F ) * tdm_powf ( cos_alpha, n );
+}
+TD V3 phong_eval ( const Surface& sf, V3 wi, V3 wo ) {
+    float kd, ks; phong_kd_ks ( sf, kd, ks );
+    float n = sf.attr[2].x;
+    V3 diffuse_term = sf.attr[1] * ( kd * 1.f / TERRA_PI_F );
+    V3 wr = phong_reflect ( sf, wo );
+    float cos_alpha = dot ( wi, wr );
+    float cos_n_alpha = tdm_powf ( cos_alpha, n );
+    V3 specular_term = sf.attr[0] * ( ks * cos_n_alpha * ( n + 2 ) / ( 2 * TERRA_PI_F ) );
+    return diffuse_term + specular_term;
+}
+
+TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
+    if ( sf.bsdf == kDevBsdfPhong ) return phong_sample ( sf, e1, e2, e3, wo );
+    return diffuse_sample ( sf, e1, e2 );
+}
+TD float bsdf_pdf ( const Surface& sf, V3 wi, V3 wo ) {
+    if ( sf.bsdf == kDevBsdfPhong ) return phong_pdf ( sf, wi, wo );
+    return diffuse_pdf ( sf, wi );
+}
+TD V3 bsdf_eval ( const Surface& sf, V3 wi, V3 wo ) {
+    if ( sf.bsdf == kDevBsdfPhong ) return phong_eval ( sf, wi, wo );
+    return diffuse_eval ( sf );
+}
+
+// -----------------------------------------------------------------------------
+// lights and integrators
+// -----------------------------------------------------------------------------
+TD float randf ( Pcg32& b, Counters& c, bool count ) { if ( count ) ++c.rand_calls; return trng_b_float ( b ); }
+
+TD float triangle_area ( V3 a, V3 b, V3 cc ) { return length ( cross ( b - a, cc - a ) ) / 2; }
+
+struct LightSample { uint32_t light_object; uint32_t tri_in_object; uint32_t tri; float pick_pdf; V3 pos, norm; };
+
+template <bool COUNT>
+TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c ) {
+    LightSample ls;
+    float e = ( float ) ( ( double ) randf ( rb, c, COUNT ) - 1e-4 );
+    double xl = ( double ) e * ( double ) sc.n_lights;
+    uint32_t li = xl < 0 ? 0u : ( uint32_t ) xl;
+    ls.pick_pdf = 1.f / ( float ) sc.lights_triangles_count;
+    DevLight l = sc.lights[li];
+    float e_t = randf ( rb, c, COUNT );
+    uint32_t k = ( uint32_t ) ( e_t * ( float ) l.tri_count );
+    if ( k >= l.tri_count ) k = l.tri_count - 1;
+    ls.light_object = l.object; ls.tri_in_object = k; ls.tri = l.first_tri + k;
+    float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
+    const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
+    const float4* props = reinterpret_cast<const float4*> ( sc.props );
+    float4 t0 = tris[3 * ls.tri + 0], t1 = tris[3 * ls.tri + 1], t2 = tris[3 * ls.tri + 2];
+    float4 p0 = props[4 * ls.tri + 0], p1 = props[4 * ls.tri + 1], p2 = props[4 * ls.tri + 2];
+    float s = sqrtf ( e1 );
+    float a = 1 - s, b = e2 * s, cw = 1 - a - b;
+    ls.pos = ( v3 ( t0.x, t0.y, t0.z ) * a + v3 ( t1.x, t1.y, t1.z ) * b ) + v3 ( t2.x, t2.y, t2.z ) * cw;
+    V3 n = ( v3 ( p0.x, p0.y, p0.z ) * a + v3 ( p0.w, p1.x, p1.y ) * b ) + v3 ( p1.z, p1.w, p2.x ) * cw;
+    ls.norm = normalize ( n );
+    return ls;
+}
+
+template <bool COUNT>
+TD V3 integrate_direct ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, int* stack, int stride, Counters& c ) {
+    V3 Lo = v3 ( 0, 0, 0 );
+    if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
+    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    V3 p_to_light = ls.pos - p;
+    V3 wi = normalize ( p_to_light );
+    Surface lsf;
+    Ray r = surface_ray ( sf, p, wi, 1.f );
+    RaycastResult h = scene_raycast<COUNT> ( sc, r, lsf, stack, stride, c );
+    if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
+        float cosv = dot ( neg ( wi ), ls.norm );
+        if ( cosv > 0 ) {
+            V3 f = bsdf_eval ( sf, wi, wo );
+            float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[h.tri] );
+            V3 Ld = had ( lsf.emissive, f );
+            Ld = Ld * ( dot ( wi, sf.normal ) / ( pdf * ls.pick_pdf ) );
+            Lo = Lo + Ld;
+        }
+    }
+    return had ( Lo, throughput );
+}
+
+template <bool COUNT, bool DEBUG_WEIGHTS>
+TD V3 integrate_mis ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, int* stack, int stride, Counters& c ) {
+    V3 Lo = v3 ( 0, 0, 0 );
+    if ( DEBUG_WEIGHTS ) { if ( bounce != 0 ) return Lo; }
+    else if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
+    float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT ), e3 = randf ( rb, c, COUNT );
+    V3 bsdf_dir = bsdf_sample ( sf, e1, e2, e3, wo );
+    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    {
+        V3 p_to_light = ls.pos - p;
+        V3 wi = normalize ( p_to_light );
+        Surface lsf;
+        Ray r = surface_ray ( sf, p, wi, 1.f );
+        RaycastResult h = scene_raycast<COUNT> ( sc, r, lsf, stack, stride, c );
+        if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
+            float cosv = dot ( ls.norm, neg ( wi ) );
+            if ( cosv > 0 ) {
+                float bpdf = bsdf_pdf ( sf, wi, wo );
+                float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[h.tri] );
+                if ( DEBUG_WEIGHTS ) {
+                    float weight = ( bpdf * bpdf ) / ( lpdf * lpdf + bpdf * bpdf );
+                    Lo = Lo + v3 ( 0, 0, weight );
+                } else {
+                    float weight = ( lpdf * lpdf ) / ( lpdf * lpdf + bpdf * bpdf );
+                    if ( lpdf != 0 ) {
+                        V3 f = bsdf_eval ( sf, wi, wo );
+                        V3 L = had ( lsf.emissive, f );
+                        L = L * ( dot ( wi, sf.normal ) * weight / ( lpdf * ls.pick_pdf ) );
+                        Lo = Lo + L;
+                    }
+                }
+            }
+        }
+    }
+    {
+        V3 wi = bsdf_dir;
+        V3 f = bsdf_eval ( sf, wi, wo );
+        float bpdf = bsdf_pdf ( sf, wi, wo );
+        V3 light_wo = neg ( wi );
+        Surface lsf;
+        Ray r = surface_ray ( sf, p, wi, 1.f );
+        RaycastResult h = scene_raycast<COUNT> ( sc, r, lsf, stack, stride, c );
+        if ( h.hit && h.object == ls.light_object ) {
+            float NoW = dot ( lsf.normal, light_wo );
+            if ( NoW > 0 ) {
+                V3 dl = p - h.point;
+                float dist = dot ( dl, dl );
+                const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
+                float4 t0 = tris[3 * h.tri + 0], t1 = tris[3 * h.tri + 1], t2 = tris[3 * h.tri + 2];
+                float area = triangle_area ( v3 ( t0.x, t0.y, t0.z ), v3 ( t1.x, t1.y, t1.z ), v3 ( t2.x, t2.y, t2.z ) );
+                float lpdf = dist / ( NoW * area );
+                float weight = ( bpdf * bpdf ) / ( lpdf * lpdf + bpdf * bpdf );
+                if ( DEBUG_WEIGHTS ) {
+                    Lo = Lo + v3 ( weight, 0, 0 );
+                } else if ( bpdf != 0 ) {
+                    V3 L = had ( lsf.emissive, f );
+                    L = L * ( dot ( wi, sf.normal ) * weight / bpdf );
+                    Lo = Lo + L;
+                }
+            }
+        }
+    }
+    return had ( Lo, throughput );
+}
+
+TD V3 integrate_debug_normals ( const Surface& sf, uint32_t bounce ) {
+    if ( bounce != 0 ) return v3 ( 0, 0, 0 );
+    V3 n = sf.normal;
+    V3 pp = v3 ( sel_min ( n.x > 0 ? n.x : 0.f, 1.f ), sel_min ( n.y > 0 ? n.y : 0.f, 1.f ), sel_min ( n.z > 0 ? n.z : 0.f, 1.f ) );
+    V3 nn = v3 ( sel_min ( n.x > -1 ? n.x : -1.f, 0.f ), sel_min ( n.y > -1 ? n.y : -1.f, 0.f ), sel_min ( n.z > -1 ? n.z : -1.f, 0.f ) );
+    nn = nn * -1.f;
+    V3 col = v3 ( 0, 0, 0 );
+    col = col + v3 ( 1, 0, 0 ) * pp.x;
+    col = col + v3 ( 0, 1, 0 ) * pp.y;
+    col = col + v3 ( 0, 0, 1 ) * pp.z;
+    col = col + v3 ( 0, 1, 1 ) * nn.x;
+    col = col + v3 ( 1, 0, 1 ) * nn.y;
+    col = col + v3 ( 1, 1, 0 ) * nn.z;
+    return col;
+}
+
+// integrator ids = TerraIntegrator (reference include/Terra.h:149-157)
+template <int INTEGRATOR, bool COUNT>
+TD V3 integrate ( const DevScene& sc, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, int* stack, int stride, Counters& c ) {
+    if ( INTEGRATOR == 0 ) {
+        if ( dot ( wo, sf.normal ) > 0 ) return had ( sf.emissive, throughput );
+        return v3 ( 0, 0, 0 );
+    } else if ( INTEGRATOR == 1 ) {
+        return integrate_direct<COUNT> ( sc, sf, p, wo, throughput, bounce, rb, stack, stride, c );
+    } else if ( INTEGRATOR == 2 ) {
+        return integrate_mis<COUNT, false> ( sc, sf, p, wo, throughput, bounce, rb, stack, stride, c );
+    } else if ( INTEGRATOR == 3 ) {
+        return bounce != 0 ? v3 ( 0, 0, 0 ) : v3 ( 1, 1, 1 );
+    } else if ( INTEGRATOR == 4 ) {
+        if ( bounce != 0 ) return v3 ( 0, 0, 0 );
+        float d = length ( ray.o - p ) / 500.f;
+        return v3 ( d, d, d );
+    } else if ( INTEGRATOR == 5 ) {
+        return integrate_debug_normals ( sf, bounce );
+    } else {
+        return integrate_mis<COUNT, true> ( sc, sf, p, wo, throughput, bounce, rb, stack, stride, c );
+    }
+}
+
+// -----------------------------------------------------------------------------
+// one full path (the reference's terra_trace), used by the unit entry point and,
+// restructured with path regeneration, by the render kernel
+// -----------------------------------------------------------------------------
+template <int INTEGRATOR, bool COUNT>
+TD V3 trace_path ( const DevScene& sc, Ray ray, uint32_t bounces, Pcg32& rb, int* stack, int stride, Counters& c ) {
+    V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
+    for ( uint32_t bounce = 0; bounce <= bounces; ++bounce ) {
+        Surface sf;
+        RaycastResult h = scene_raycast<COUNT> ( sc, ray, sf, stack, stride, c );
+        if ( !h.hit ) break;
+        V3 wo = neg ( ray.d );
+        Lo = Lo + integrate<INTEGRATOR, COUNT> ( sc, ray, sf, h.point, wo, throughput, bounce, rb, stack, stride, c );
+        float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
+        V3 wi = bsdf_sample ( sf, e0, e1, e2, wo );
+        float pdf = sel_max ( bsdf_pdf ( sf, wi, wo ), ( float ) 1e-4 );
+        V3 f = bsdf_eval ( sf, wi, wo ) * ( 1.f / pdf );
+        throughput = had ( throughput, f );
+        throughput = throughput * dot ( sf.normal, wi );
+        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
+        float e3 = randf ( rb, c, COUNT );
+        if ( e3 > pr ) break;
+        throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+        ray = surface_ray ( sf, h.point, wi, 1.f );
+    }
+    return Lo;
+}
+
+// -----------------------------------------------------------------------------
+// tonemap
+// -----------------------------------------------------------------------------
+TD V3 uncharted2 ( V3 x ) {
+    const float A = 0.15f, B = 0.5f, C = 0.1f, D = 0.2f, E = 0.02f, F = 0.3f;
+    V3 r;
+    r.x = ( ( x.x * ( A * x.x + C * B ) + D * E ) / ( x.x * ( A * x.x + B ) + D * F ) ) - E / F;
+    r.y = ( ( x.y * ( A * x.y + C * B ) + D * E ) / ( x.y * ( A * x.y + B ) + D * F ) ) - E / F;
+    r.z = ( ( x.z * ( A * x.z + C * B ) + D * E ) / ( x.z * ( A * x.z + B ) + D * F ) ) - E / F;
+    return r;
+}
+TD V3 powv ( V3 c, float e ) { return v3 ( tdm_powf ( c.x, e ), tdm_powf ( c.y, e ), tdm_powf ( c.z, e ) ); }
+TD V3 tonemap ( V3 c, int op, float gamma ) {
+    switch ( op ) {
+        case 1: c = powv ( c, 1.f / gamma ); break;
+        case 2:
+            c.x = c.x / ( 1.f + c.x ); c.y = c.y / ( 1.f + c.y ); c.z = c.z / ( 1.f + c.z );
+            c = powv ( c, 1.f / gamma ); break;
+        case 3: {
+            V3 x = v3 ( sel_max ( 0.f, c.x - 0.004f ), sel_max ( 0.f, c.y - 0.004f ), sel_max ( 0.f, c.z - 0.004f ) );
+            c.x = ( x.x * ( 6.2f * x.x + 0.5f ) ) / ( x.x * ( 6.2f * x.x + 1.7f ) + 0.06f );
+            c.y = ( x.y * ( 6.2f * x.y + 0.5f ) ) / ( x.y * ( 6.2f * x.y + 1.7f ) + 0.06f );
+            c.x = ( x.z * ( 6.2f * x.z + 0.5f ) ) / ( x.z * ( 6.2f * x.z + 1.7f ) + 0.06f );   // the reference stores the .z curve in .x
+            break;
+        }
+        case 4: {
+            V3 ws = uncharted2 ( v3 ( 11.2f, 11.2f, 11.2f ) );
+            ws = v3 ( 1.f / ws.x, 1.f / ws.y, 1.f / ws.z );
+            V3 t = uncharted2 ( c * 2.f );
+            c = powv ( had ( t, ws ), 1.f / gamma );
+            break;
+        }
+        default: break;
+    }
+    return c;
+}

@@ -1,0 +1,210 @@
+// unit_kernels.hip -- one-function-per-kernel wrappers over the device functions
+// of trace_device.h, so parity tests can pin every stage of the path against the
+// oracle and the golden vectors (include/terra_amd.h, "unit-level device entry points").
+#include <hip/hip_runtime.h>
+#include "trace_device.h"
+#include "kernels.h"
+
+#define UNIT_GRID(n) dim3 ( ( ( n ) + 255 ) / 256 ), dim3 ( 256 )
+
+__global__ void k_pcg ( const uint32_t* seeds, int nseeds, int n, float* out ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= nseeds ) return;
+    Pcg32 a; a.state = 0; a.inc = 1;
+    trng_next ( a ); a.state += seeds[i]; trng_next ( a );
+    for ( int j = 0; j < n; ++j ) out[ ( size_t ) i * n + j] = trng_a_float ( a );
+}
+hipError_t terra_unit_pcg ( const uint32_t* seeds, int nseeds, int n, float* out ) {
+    hipLaunchKernelGGL ( k_pcg, UNIT_GRID ( nseeds ), 0, 0, seeds, nseeds, n, out );
+    return hipGetLastError();
+}
+
+__global__ void k_stream_keys ( uint64_t seed, const uint64_t* pix, const uint64_t* k, int n, uint64_t* out3 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    PixelStreams s = trng_pixel_streams ( seed, pix[i], k[i] );
+    out3[3 * i] = s.seedA; out3[3 * i + 1] = s.b.state; out3[3 * i + 2] = s.b.inc;
+}
+hipError_t terra_unit_stream_keys ( uint64_t frame_seed, const uint64_t* pix, const uint64_t* k, int n, uint64_t* out3 ) {
+    hipLaunchKernelGGL ( k_stream_keys, UNIT_GRID ( n ), 0, 0, frame_seed, pix, k, n, out3 );
+    return hipGetLastError();
+}
+
+__global__ void k_ray_aabb ( int n, const float* o, const float* d, const float* boxes, int* hit, float* tmin, float* tmax ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
+    float a, b;
+    bool h = ray_aabb ( r, v3p ( boxes + 6 * i ), v3p ( boxes + 6 * i + 3 ), &a, &b );
+    hit[i] = h ? 1 : 0;
+    if ( h ) { tmin[i] = a; tmax[i] = b; }
+}
+hipError_t terra_unit_ray_aabb ( int n, const float* o, const float* d, const float* boxes, int* hit, float* tmin, float* tmax ) {
+    hipLaunchKernelGGL ( k_ray_aabb, UNIT_GRID ( n ), 0, 0, n, o, d, boxes, hit, tmin, tmax );
+    return hipGetLastError();
+}
+
+__global__ void k_watertight ( int n, const float* o, const float* d, const float* tris, int* hit, float* out8 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
+    RayState s = ray_state_init ( r );
+    TriHit h; h.u = h.v = h.w = h.depth = 0.f; h.point = v3 ( 0, 0, 0 );
+    bool ok = watertight ( r, s, v3p ( tris + 9 * i ), v3p ( tris + 9 * i + 3 ), v3p ( tris + 9 * i + 6 ), h );
+    hit[i] = ok ? 1 : 0;
+    float* q = out8 + 8 * i;
+    if ( ok ) { q[0] = h.u; q[1] = h.v; q[2] = h.w; q[3] = h.depth; q[4] = h.point.x; q[5] = h.point.y; q[6] = h.point.z; q[7] = 0.f; }
+    else { for ( int j = 0; j < 8; ++j ) q[j] = 0.f; }
+}
+hipError_t terra_unit_watertight ( int n, const float* o, const float* d, const float* tris, int* hit, float* out8 ) {
+    hipLaunchKernelGGL ( k_watertight, UNIT_GRID ( n ), 0, 0, n, o, d, tris, hit, out8 );
+    return hipGetLastError();
+}
+
+__global__ void k_mt ( int n, const float* o, const float* d, const float* tris, int* hit, float* out4 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    float t = 0.f; V3 p = v3 ( 0, 0, 0 );
+    bool ok = moller_trumbore ( v3p ( o + 3 * i ), v3p ( d + 3 * i ), v3p ( tris + 9 * i ), v3p ( tris + 9 * i + 3 ), v3p ( tris + 9 * i + 6 ), t, p );
+    hit[i] = ok ? 1 : 0;
+    out4[4 * i] = ok ? t : 0.f; out4[4 * i + 1] = ok ? p.x : 0.f; out4[4 * i + 2] = ok ? p.y : 0.f; out4[4 * i + 3] = ok ? p.z : 0.f;
+}
+hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, const float* tris, int* hit, float* out4 ) {
+    hipLaunchKernelGGL ( k_mt, UNIT_GRID ( n ), 0, 0, n, o, d, tris, hit, out4 );
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
+    extern __shared__ int lds_stack[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
+    RayState s = ray_state_init ( r );
+    Counters c = counters_zero();
+    Closest b = bvh_traverse<false> ( sc, r, s, lds_stack + threadIdx.x, 256, c );
+    found[i] = b.found ? 1 : 0;
+    prim[i] = b.found ? b.prim : 0u;
+    point[3 * i] = b.point.x; point[3 * i + 1] = b.point.y; point[3 * i + 2] = b.point.z;
+}
+static size_t stack_lds ( const DevScene& sc ) { return ( size_t ) ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 * sizeof ( int ); }
+hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
+    hipLaunchKernelGGL ( k_bvh_traverse, UNIT_GRID ( n ), stack_lds ( sc ), 0, sc, n, o, d, found, prim, point );
+    return hipGetLastError();
+}
+
+__device__ void surface_to_floats ( const DevScene& sc, const Surface& sf, uint32_t object, float* q ) {
+    q[0] = sf.basis.r0[0]; q[1] = sf.basis.r0[1]; q[2] = sf.basis.r0[2]; q[3] = 0.f;
+    q[4] = sf.basis.r1[0]; q[5] = sf.basis.r1[1]; q[6] = sf.basis.r1[2]; q[7] = 0.f;
+    q[8] = sf.basis.r2[0]; q[9] = sf.basis.r2[1]; q[10] = sf.basis.r2[2]; q[11] = 0.f;
+    q[12] = 0.f; q[13] = 0.f; q[14] = 0.f; q[15] = 1.f;
+    q[16] = sf.normal.x; q[17] = sf.normal.y; q[18] = sf.normal.z;
+    q[19] = sf.emissive.x; q[20] = sf.emissive.y; q[21] = sf.emissive.z;
+    q[22] = sc.mats[object].ior;
+    for ( int a = 0; a < 8; ++a ) for ( int k = 0; k < 3; ++k ) q[23 + 3 * a + k] = sc.mats[object].attributes[a][k];
+}
+__global__ __launch_bounds__ ( 256 ) void k_raycast ( DevScene sc, int n, const float* o, const float* d, int* obj, int* tri, float* point, float* surface47 ) {
+    extern __shared__ int lds_stack[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
+    Counters c = counters_zero();
+    Surface sf;
+    RaycastResult h = scene_raycast<false> ( sc, r, sf, lds_stack + threadIdx.x, 256, c );
+    obj[i] = h.hit ? ( int ) h.object : -1;
+    tri[i] = h.hit ? ( int ) h.tri_in_object : 0;
+    point[3 * i] = h.point.x; point[3 * i + 1] = h.point.y; point[3 * i + 2] = h.point.z;
+    float* q = surface47 + 47 * ( size_t ) i;
+    if ( h.hit ) surface_to_floats ( sc, sf, h.object, q );
+    else for ( int j = 0; j < 47; ++j ) q[j] = 0.f;
+}
+hipError_t terra_unit_raycast ( const DevScene& sc, int n, const float* o, const float* d, int* obj, int* tri, float* point, float* surface47 ) {
+    hipLaunchKernelGGL ( k_raycast, UNIT_GRID ( n ), stack_lds ( sc ), 0, sc, n, o, d, obj, tri, point, surface47 );
+    return hipGetLastError();
+}
+
+template <int I>
+__global__ __launch_bounds__ ( 256 ) void k_trace ( DevScene sc, uint32_t bounces, int n, const float* o, const float* d, const uint64_t* stateB, const uint64_t* incB, float* radiance, uint32_t* rand_calls ) {
+    extern __shared__ int lds_stack[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
+    Pcg32 b; b.state = stateB[i]; b.inc = incB[i];
+    Counters c = counters_zero();
+    V3 L = trace_path<I, true> ( sc, r, bounces, b, lds_stack + threadIdx.x, 256, c );
+    radiance[3 * i] = L.x; radiance[3 * i + 1] = L.y; radiance[3 * i + 2] = L.z;
+    rand_calls[i] = c.rand_calls;
+}
+hipError_t terra_unit_trace ( const DevScene& sc, int integrator, uint32_t bounces, int n, const float* o, const float* d,
+                              const uint64_t* stateB, const uint64_t* incB, float* radiance, uint32_t* rand_calls ) {
+#define TRACE_CASE(I) case I: hipLaunchKernelGGL ( k_trace<I>, UNIT_GRID ( n ), stack_lds ( sc ), 0, sc, bounces, n, o, d, stateB, incB, radiance, rand_calls ); break;
+    switch ( integrator ) {
+        TRACE_CASE ( 0 ) TRACE_CASE ( 1 ) TRACE_CASE ( 2 ) TRACE_CASE ( 3 ) TRACE_CASE ( 4 ) TRACE_CASE ( 5 ) TRACE_CASE ( 6 )
+        default: return hipErrorInvalidValue;
+    }
+#undef TRACE_CASE
+    return hipGetLastError();
+}
+
+__global__ void k_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    float* q = surfaces47 + 47 * ( size_t ) i;
+    Surface sf;
+    sf.basis.r0[0] = q[0]; sf.basis.r0[1] = q[1]; sf.basis.r0[2] = q[2];
+    sf.basis.r1[0] = q[4]; sf.basis.r1[1] = q[5]; sf.basis.r1[2] = q[6];
+    sf.basis.r2[0] = q[8]; sf.basis.r2[1] = q[9]; sf.basis.r2[2] = q[10];
+    sf.normal = v3p ( q + 16 ); sf.emissive = v3p ( q + 19 );
+    for ( int a = 0; a < 4; ++a ) sf.attr[a] = v3p ( q + 23 + 3 * a );
+    sf.bsdf = kind;
+    V3 wo = v3p ( wo3 + 3 * i );
+    V3 wi = bsdf_sample ( sf, e3[3 * i], e3[3 * i + 1], e3[3 * i + 2], wo );
+    float p = bsdf_pdf ( sf, wi, wo );
+    V3 f = bsdf_eval ( sf, wi, wo );
+    wi3[3 * i] = wi.x; wi3[3 * i + 1] = wi.y; wi3[3 * i + 2] = wi.z;
+    pdf[i] = p;
+    f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
+    q[23 + 9] = sf.attr[3].x;
+}
+hipError_t terra_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 ) {
+    hipLaunchKernelGGL ( k_bsdf, UNIT_GRID ( n ), 0, 0, kind, n, surfaces47, e3, wo3, wi3, pdf, f3 );
+    return hipGetLastError();
+}
+
+__global__ void k_camera ( DevRenderParams p, int n, const uint32_t* xy2, const float* r2, float* dirs3 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    V3 d = camera_sample ( p, xy2[2 * i], xy2[2 * i + 1], r2[2 * i], r2[2 * i + 1] );
+    dirs3[3 * i] = d.x; dirs3[3 * i + 1] = d.y; dirs3[3 * i + 2] = d.z;
+}
+hipError_t terra_unit_camera ( const DevRenderParams& p, int n, const uint32_t* xy2, const float* r2, float* dirs3 ) {
+    hipLaunchKernelGGL ( k_camera, UNIT_GRID ( n ), 0, 0, p, n, xy2, r2, dirs3 );
+    return hipGetLastError();
+}
+
+__global__ void k_tonemap ( int op, float gamma, int n, float* c3 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    V3 c = tonemap ( v3p ( c3 + 3 * i ), op, gamma );
+    c3[3 * i] = c.x; c3[3 * i + 1] = c.y; c3[3 * i + 2] = c.z;
+}
+hipError_t terra_unit_tonemap ( int op, float gamma, int n, float* colors3 ) {
+    hipLaunchKernelGGL ( k_tonemap, UNIT_GRID ( n ), 0, 0, op, gamma, n, colors3 );
+    return hipGetLastError();
+}
+
+__global__ void k_math ( int fn, int n, const float* x, const float* y, float* out ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    float r;
+    switch ( fn ) {
+        case 0: r = tdm_sinf ( x[i] ); break;
+        case 1: r = tdm_cosf ( x[i] ); break;
+        case 2: r = tdm_powf ( x[i], y[i] ); break;
+        default: r = tdm_acosf ( x[i] ); break;
+    }
+    out[i] = r;
+}
+hipError_t terra_unit_math ( int fn, int n, const float* x, const float* y, float* out ) {
+    hipLaunchKernelGGL ( k_math, UNIT_GRID ( n ), 0, 0, fn, n, x, y, out );
+    return hipGetLastError();
+}
