@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] -- the Cornell box at
+1920x1080, 512 spp, max 8 bounces (Simple integrator, random sampler, jitter 0.5,
+tonemap None) -- rendered through the product's
+device-resident entry point terra_amd_render_device[_sharded] (the framebuffer
+is already in HBM when the timed region starts; terra_render()'s PCIe-inclusive
+rate is reported in DESIGN.md, never here).
+
+A step = one pass of the hot path over the whole frame: every pixel receives
+spp more samples. With N ranks (one process per GPU) the frame's 64x64 tiles are
+dealt round-robin to the ranks (t % N == rank), each rank renders its tiles on
+its own scene replica, and ONE gather (RCCL over xGMI) moves the packed tiles to
+rank 0, which unpacks them into the full frame. Total work is fixed as N grows:
+"scaling": "strong". value = frame samples * K / max-over-ranks wall time.
+
+Also on the JSON line (rank 0):
+  roofline     -- the render kernel's ALGORITHMIC bytes per launch (device work
+                  counters x SURVEY.md 8d's per-unit sizes) / its average launch
+                  duration measured with HIP events on the launch stream, against
+                  the 8 TB/s HBM peak; traffic = measured HBM bytes per launch
+                  from the committed rocprofv3 PMC passes (profiles/), or null.
+  cpu_baseline -- the oracle (CPU restatement, bit-exact to the reference) on all
+                  host cores over a bounded crop of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch  # before the library: it must bind to the HIP runtime torch loads
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from terra_amd import api, runtime, scenes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TILE = 64
+
+
+def algorithmic_bytes(st: dict) -> float:
+    """64 B per node popped, 36 B per triangle test, 36+60 B per hit,
+    12 B per attribute fetched, 44 B per pixel per call (reference struct sizes, not the padded device ones)."""
+    return 64.0 * st["nodes"] + 36.0 * st["tri_tests"] + 96.0 * st["hits"] + 12.0 * st["attr_fetches"] + 44.0 * st["pixels"]
+
+
+def workload(name: str, spp_override):
+    if name == "cornell_1080p_512spp":
+        d = scenes.cornell_box(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorSimple)
+    elif name == "cornell_256_4spp":
+        d = scenes.cornell_box(256, 256, 4, bounces=8, integrator=api.kTerraIntegratorSimple)
+    elif name == "cornell_1080p_512spp_direct":
+        d = scenes.cornell_box(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorDirect)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    if spp_override:
+        d.spp = spp_override
+    return d
+
+
+def usable_cores() -> int:
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 20.0):
+    """Oracle (port of the reference, libm math) on every host core over a centred crop at full spp."""
+    import subprocess
+    subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    orc = api.TerraLib(ROOT / "oracle" / "liboracle.so", "orc_")
+    cores = usable_cores()
+    f = orc.fn("orc_render_pixels_mt", None, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 4 + [C.c_uint64, C.c_void_p, C.c_int])
+    scene = scenes.build_scene(orc, d)
+    cam = scenes.camera_of(d)
+    fb = api.Framebuffer(orc, d.width, d.height)
+    # calibrate on a thin strip, then size the crop for ~seconds_budget
+    cw = min(d.width, 512); x0 = (d.width - cw) // 2; y0 = d.height // 2
+    rows0 = max(2, cores)
+    t = time.perf_counter(); f(C.byref(cam), scene, C.byref(fb.fb), x0, y0, cw, rows0, scenes.FRAME_SEED, None, cores); dt = time.perf_counter() - t
+    rate = cw * rows0 * d.spp / max(dt, 1e-6)
+    rows = int(max(8, min(d.height // 2, seconds_budget * rate / (cw * d.spp))))
+    y1 = max(0, d.height // 2 - rows // 2)
+    fb.clear()
+    t = time.perf_counter(); f(C.byref(cam), scene, C.byref(fb.fb), x0, y1, cw, rows, scenes.FRAME_SEED, None, cores); dt = time.perf_counter() - t
+    val = cw * rows * d.spp / dt / 1e6
+    fb.destroy(); orc.scene_destroy(scene)
+    return {"value": round(val, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cw}x{rows} crop at x={x0},y={y1} of the {d.width}x{d.height} frame, full {d.spp} spp, {dt:.1f} s, oracle/liboracle.so on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_1080p_512spp")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    lib = runtime.load()
+    if lib.device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: " + runtime.last_error())
+    runtime.check(lib.set_device(dev.index), "terra_amd_set_device")
+
+    d = workload(args.workload, args.spp)
+    scene = scenes.build_scene(lib, d)
+    if runtime.last_error():
+        raise SystemExit("scene commit failed: " + runtime.last_error())
+    cam = scenes.camera_of(d)
+    fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
+    n_packed = runtime.packed_floats_per_rank(d.width, d.height, TILE, world)
+    packed = torch.zeros(n_packed, dtype=torch.float32, device=dev) if world > 1 else None
+    gather_bufs = [torch.zeros(n_packed, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        if world == 1:
+            runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, stream), "render")
+        else:
+            runtime.check(lib.render_device_sharded(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, None, stream), "render")
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:
+            runtime.check(lib.pack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, packed.data_ptr(), stream), "pack")
+            dist.gather(packed, gather_list=gather_bufs, dst=0)
+            if rank == 0:
+                for src in range(1, world):
+                    runtime.check(lib.unpack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, src, world, gather_bufs[src].data_ptr(), stream), "unpack")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    runtime.check(lib.reset_stats(scene))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    frame_samples = d.width * d.height * d.spp
+    value = frame_samples * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        alg = algorithmic_bytes(st) / max(1, st["launches"])
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "roofline_traffic.json"
+        if tf.exists() and world == 1 and not args.spp:
+            traffic = json.loads(tf.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces,
+                       "integrator": "simple" if d.integrator == 0 else ("direct" if d.integrator == 1 else str(d.integrator)),
+                       "triangles": d.triangle_count, "tile": TILE, "parallelism": f"tiles%{world}" if world > 1 else "single"},
+            "mrays_per_s": round(st["rays"] / max(1, st["launches"]) * (1 if world == 1 else world) / (kernel_ms * 1e-3) / 1e6, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "algorithmic_bytes_per_launch": int(alg), "rank0_only": world > 1},
+            "counters_per_launch": {k: v // max(1, st["launches"]) for k, v in st.items() if k != "launches"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1089,3 +1089,31 @@ size_t orc_lights_triangles_count ( HTerraScene h ) { return ( ( OrcScene* ) h )
 int    orc_light_object_index ( HTerraScene h, size_t i ) { return ( ( OrcScene* ) h )->lights[i].object; }
 float  orc_light_area ( HTerraScene h, size_t i ) { return ( ( OrcScene* ) h )->lights[i].area; }
 const float* orc_light_triangle_areas ( HTerraScene h, size_t i ) { return ( ( OrcScene* ) h )->lights[i].triangle_area; }
+
+/* ------------------------------------------------------------------------- */
+/* devmath checks (tests/test_oracle_math.py)                                  */
+/* ------------------------------------------------------------------------- */
+/* every theta the diffuse sampler can produce: 2*terra_PI*(k*2^-24), k in [0,2^24) (reference src/TerraPresets.c:38) */
+void orc_devmath_sincos_domain_check ( uint64_t* sin_mismatch, uint64_t* cos_mismatch ) {
+    uint64_t bs = 0, bc = 0;
+    for ( uint32_t k = 0; k < ( 1u << 24 ); ++k ) {
+        float e2 = ( float ) k * 0x1p-24f;
+        float theta = 2 * terra_PI * e2;
+        if ( orc_dm_bits ( sinf ( theta ) ) != orc_dm_bits ( orc_dm_sinf ( theta ) ) ) ++bs;
+        if ( orc_dm_bits ( cosf ( theta ) ) != orc_dm_bits ( orc_dm_cosf ( theta ) ) ) ++bc;
+    }
+    *sin_mismatch = bs; *cos_mismatch = bc;
+}
+/* fn: 0 sinf 1 cosf 2 powf 3 acosf; mode: ORC_MATH_LIBM / ORC_MATH_DEVMATH */
+void orc_math_eval ( int fn, int mode, int n, const float* x, const float* y, float* out ) {
+    for ( int i = 0; i < n; ++i ) {
+        if ( mode == ORC_MATH_LIBM ) out[i] = fn == 0 ? sinf ( x[i] ) : fn == 1 ? cosf ( x[i] ) : fn == 2 ? powf ( x[i], y[i] ) : acosf ( x[i] );
+        else out[i] = fn == 0 ? orc_dm_sinf ( x[i] ) : fn == 1 ? orc_dm_cosf ( x[i] ) : fn == 2 ? orc_dm_powf ( x[i], y[i] ) : orc_dm_acosf ( x[i] );
+    }
+}
+
+/* stream keys of one pixel: out3 = { seedA, stateB, incB } (stream_key.h) */
+void orc_pixel_stream_key ( uint64_t frame_seed, uint64_t pix, uint64_t samples_so_far, uint64_t* out3 ) {
+    OrcPixelStreams s = orc_pixel_streams ( frame_seed, pix, samples_so_far );
+    out3[0] = s.seedA; out3[1] = s.streamB.state; out3[2] = s.streamB.inc;
+}

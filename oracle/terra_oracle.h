@@ -109,6 +109,9 @@ float       orc_math_sinf ( float x );
 float       orc_math_cosf ( float x );
 float       orc_math_powf ( float x, float y );
 float       orc_math_acosf ( float x );
+void        orc_devmath_sincos_domain_check ( uint64_t* sin_mismatch, uint64_t* cos_mismatch );
+void        orc_math_eval ( int fn, int mode, int n, const float* x, const float* y, float* out );
+void        orc_pixel_stream_key ( uint64_t frame_seed, uint64_t pix, uint64_t samples_so_far, uint64_t* out3 );
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,161 @@
+"""Host-side runtime helpers around libterra_amd.so.
+
+PyTorch is used only as plumbing: device memory (framebuffers are torch tensors
+whose data_ptr() is handed to the C-ABI), streams and torch.distributed (RCCL).
+Import order matters on this image: torch ships its own libamdhip64.so.7, so
+torch is imported BEFORE the library is dlopen'ed and the library binds to the
+runtime torch already loaded (two HIP runtimes in one process do not see each
+other's devices).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import api, scenes
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libterra_amd.so"
+
+_lib: Optional[api.TerraLib] = None
+
+
+class TerraAmdError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "box_tests", "tri_tests", "hits", "samples", "rand_calls", "attr_fetches", "pixels", "launches")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("triangles", C.c_uint32), ("nodes", C.c_uint32), ("objects", C.c_uint32), ("lights", C.c_uint32),
+                ("lights_triangles_count", C.c_uint32), ("max_stack", C.c_int32), ("device_bytes", C.c_uint64)]
+
+
+_CAM = C.POINTER(api.TerraCamera)
+_SZ = C.c_size_t
+_EXTRA = {
+    "terra_amd_last_error": (C.c_char_p, []),
+    "terra_amd_clear_error": (None, []),
+    "terra_amd_device_count": (C.c_int, []),
+    "terra_amd_set_device": (C.c_int, [C.c_int]),
+    "terra_amd_get_device": (C.c_int, []),
+    "terra_amd_set_frame_seed": (None, [C.c_void_p, C.c_uint64]),
+    "terra_amd_get_frame_seed": (C.c_uint64, [C.c_void_p]),
+    "terra_amd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "terra_amd_reset_stats": (C.c_int, [C.c_void_p]),
+    "terra_amd_scene_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
+    "terra_amd_scene_bvh_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "terra_amd_render_device": (C.c_int, [_CAM, C.c_void_p, C.c_void_p, C.c_void_p] + [_SZ] * 6 + [C.c_void_p, C.c_void_p]),
+    "terra_amd_render_device_sharded": (C.c_int, [_CAM, C.c_void_p, C.c_void_p, C.c_void_p] + [_SZ] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "terra_amd_shard_tile_count": (C.c_int, [_SZ, _SZ, _SZ, C.c_int, C.c_int]),
+    "terra_amd_shard_packed_bytes": (_SZ, [_SZ, _SZ, _SZ, C.c_int]),
+    "terra_amd_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p] + [_SZ] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "terra_amd_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p] + [_SZ] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "terra_amd_synchronize": (C.c_int, [C.c_void_p]),
+    "terra_amd_time_render_device": (C.c_int, [_CAM, C.c_void_p, C.c_void_p, C.c_void_p] + [_SZ] * 6 + [C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+
+def load(need_torch: bool = True) -> api.TerraLib:
+    """dlopen libterra_amd.so (after torch, see module docstring). Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if need_torch:
+        import torch  # noqa: F401  (loads the HIP runtime the library will bind to)
+    if not LIB_PATH.exists():
+        raise TerraAmdError(f"{LIB_PATH} is missing: run `python -m terra_amd.build` (there is no CPU fallback)")
+    lib = api.TerraLib(LIB_PATH, "terra_")
+    if lib.missing:
+        raise TerraAmdError(f"{LIB_PATH} lacks Terra.h entry points: {lib.missing}")
+    for name, (res, args) in _EXTRA.items():
+        setattr(lib, name[len("terra_amd_"):] if name.startswith("terra_amd_") else name, lib.fn(name, res, args))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        raise TerraAmdError(f"{what}: {load().last_error().decode()} (status {rc})")
+    return rc
+
+
+def last_error() -> str:
+    return load().last_error().decode()
+
+
+class DeviceFramebuffer:
+    """A TerraFramebuffer that lives in HBM: torch tensors, handed to the C-ABI as raw pointers."""
+
+    def __init__(self, width: int, height: int, device: str = "cuda"):
+        import torch
+        self.width, self.height = width, height
+        self.pixels = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
+        self.results = torch.zeros(height * width * 4, dtype=torch.int32, device=device)   # {f32 acc[3]; i32 samples}
+
+    def clear(self):
+        self.pixels.zero_(); self.results.zero_()
+
+    def pixels_host(self) -> np.ndarray:
+        return self.pixels.cpu().numpy().reshape(self.height, self.width, 3)
+
+    def results_host(self) -> np.ndarray:
+        return self.results.cpu().numpy().view(api.RESULT_DTYPE).reshape(self.height, self.width)
+
+
+def render_device(lib, cam, scene, fb: DeviceFramebuffer, rect: Optional[Tuple[int, int, int, int]] = None, rand_calls=None, stream=None):
+    x, y, w, h = rect if rect else (0, 0, fb.width, fb.height)
+    check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), fb.width, fb.height, x, y, w, h,
+                            rand_calls.data_ptr() if rand_calls is not None else None, stream), "terra_amd_render_device")
+
+
+def render_device_sharded(lib, cam, scene, fb: DeviceFramebuffer, tile: int, rank: int, world: int, stream=None):
+    check(lib.render_device_sharded(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), fb.width, fb.height,
+                                    0, 0, fb.width, fb.height, tile, rank, world, None, stream), "terra_amd_render_device_sharded")
+
+
+# ---------------------------------------------------------------------------
+# tile sharding across ranks (one process per GPU) and the single gather
+# ---------------------------------------------------------------------------
+
+def shard_tiles(width: int, height: int, tile: int, rank: int, world: int):
+    """tile ids (row-major in the frame) owned by `rank`: t % world == rank (same rule as the kernel)"""
+    tx, ty = -(-width // tile), -(-height // tile)
+    return [t for t in range(tx * ty) if t % world == rank]
+
+
+def packed_floats_per_rank(width: int, height: int, tile: int, world: int) -> int:
+    """floats in one rank's packed gather buffer (padded to rank 0's tile count): 7 floats = 28 B per pixel"""
+    tx, ty = -(-width // tile), -(-height // tile)
+    most = -(-(tx * ty) // world)
+    return most * tile * tile * 7
+
+
+def gather_frame(fb_pack, fb_unpack, width, height, tile, rank, world, dist, make_buffer, dst=0):
+    """One gather of every rank's packed tiles to `dst`, then unpack there.
+
+    fb_pack(rank) -> 1-D float32 tensor holding this rank's tiles in the packed layout
+    fb_unpack(src_rank, packed) writes rank src_rank's tiles into the destination frame (called on dst only)
+    dist: torch.distributed (backend nccl == RCCL on the GPU box, gloo in CPU tests)
+    """
+    mine = fb_pack(rank)
+    if world == 1:
+        return
+    n = packed_floats_per_rank(width, height, tile, world)
+    assert mine.numel() == n
+    if rank == dst:
+        bufs = [make_buffer(n) for _ in range(world)]
+        dist.gather(mine, gather_list=bufs, dst=dst)
+        for src in range(world):
+            if src != dst:
+                fb_unpack(src, bufs[src])
+    else:
+        dist.gather(mine, gather_list=None, dst=dst)

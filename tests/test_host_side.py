@@ -1,0 +1,153 @@
+"""Host logic of the product that runs without a GPU: BVH build in the reference's
+tree layout, scene bookkeeping, error behaviour (fail loudly, never fall back),
+framebuffer/texture API, shard helpers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from terra_amd import api, runtime, scenes
+
+
+@pytest.fixture(scope="module")
+def L(amd_lib):
+    return runtime.load(need_torch=False)
+
+
+def test_host_bvh_equals_golden_and_oracle(H, L, orc_lib):
+    d = scenes.cornell_box(256, 256, 4)
+    scene = scenes.build_scene(L, d)
+    nodes = H.Unit("amd").bvh_nodes(scene)
+    assert np.array_equal(nodes, np.load(H.GOLDEN / "bvh_cornell.npz")["nodes"])
+    info = runtime.SceneInfo()
+    assert L.scene_info(scene, C.byref(info)) == 0
+    assert (info.triangles, info.nodes, info.objects, info.lights, info.lights_triangles_count) == (32, 31, 6, 1, 2)
+    so = scenes.build_scene(orc_lib, d)
+    assert info.max_stack == orc_lib.fn("orc_bvh_max_stack", C.c_int, [C.c_void_p])(so)
+    L.scene_destroy(scene)
+
+
+@pytest.mark.parametrize("n_tris,seed", [(1, 1), (2, 2), (5, 3), (64, 4), (700, 5), (5000, 6)])
+def test_host_bvh_equals_oracle_on_random_soups(H, L, orc_lib, n_tris, seed):
+    from test_oracle_vs_reference import soup_scene
+    d = soup_scene(H, n_tris, seed, n_objects=min(3, n_tris))
+    sa, so = scenes.build_scene(L, d), scenes.build_scene(orc_lib, d)
+    assert np.array_equal(H.Unit("amd").bvh_nodes(sa), H.Unit("orc").bvh_nodes(so))
+    L.scene_destroy(sa); orc_lib.scene_destroy(so)
+
+
+def test_no_device_fails_loudly_and_renders_nothing(H, L):
+    if L.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu tests")
+    d = scenes.cornell_box(16, 16, 1)
+    L.clear_error()
+    scene = scenes.build_scene(L, d)
+    assert "no HIP device" in runtime.last_error()
+    fb = api.Framebuffer(L, 16, 16)
+    cam = scenes.camera_of(d)
+    L.clear_error()
+    L.render(C.byref(cam), scene, C.byref(fb.fb), 0, 0, 16, 16)
+    assert "no device replica" in runtime.last_error()
+    assert not fb.pixels.any() and not fb.results["samples"].any()      # nothing rendered, no CPU fallback
+    rc = L.render_device(C.byref(cam), scene, None, None, 16, 16, 0, 0, 16, 16, None, None)
+    assert rc == -1
+    L.scene_destroy(scene)
+
+
+def test_render_before_commit_is_an_error(L):
+    scene = L.scene_create()
+    L.scene_add_object(scene, 1)
+    fb = api.Framebuffer(L, 8, 8)
+    cam = scenes.camera_of(scenes.cornell_box())
+    L.clear_error()
+    L.render(C.byref(cam), scene, C.byref(fb.fb), 0, 0, 8, 8)
+    assert "commit" in runtime.last_error()
+    L.scene_destroy(scene)
+
+
+def test_foreign_bsdf_pointers_are_rejected_at_commit(H, L):
+    d = scenes.cornell_box(8, 8, 1)
+    scene = L.scene_create()
+    for od in d.objects:
+        scenes.fill_object(L, L.scene_add_object(scene, len(od.triangles)).contents, od)
+    # a client-supplied BSDF callback (allowed by the reference API) cannot run on the device
+    cb = L.malloc      # any function address that is not one of the library's preset entry points
+    objs = L.scene_add_object(scene, 1).contents
+    scenes.fill_object(L, objs, scenes.ObjectDesc(d.objects[0].triangles[:1], d.objects[0].normals[:1], d.objects[0].texcoords[:1]))
+    objs.material.bsdf.sample = C.cast(cb, C.c_void_p)
+    scenes.apply_options(L, scene, d)
+    L.clear_error()
+    L.scene_commit(scene)
+    assert "BSDF function pointers" in runtime.last_error()
+    L.scene_destroy(scene)
+
+
+def test_preset_markers_refuse_host_calls(L):
+    b = api.TerraBSDF(); L.bsdf_diffuse_init(C.byref(b))
+    f = C.CFUNCTYPE(api.TerraFloat3, C.c_void_p, C.c_void_p, C.c_void_p)(b.eval)
+    L.clear_error()
+    r = f(None, None, None)
+    assert r.tuple() == (0.0, 0.0, 0.0) and "device only" in runtime.last_error()
+    b2 = api.TerraBSDF(); L.bsdf_phong_init(C.byref(b2))
+    assert b.sample != b2.sample and b.pdf != b2.pdf and b.eval != b2.eval
+
+
+def test_framebuffer_api(L):
+    fb = api.TerraFramebuffer()
+    assert not L.framebuffer_create(C.byref(fb), 0, 4)
+    f = api.Framebuffer(L, 7, 5)
+    assert f.pixels.shape == (5, 7, 3) and not f.pixels.any() and not f.results["samples"].any()
+    f.pixels[:] = 1; f.results["samples"][:] = 3
+    f.clear()
+    assert not f.pixels.any() and not f.results["samples"].any()
+    f.destroy()
+
+
+def test_options_are_double_buffered(L):
+    scene = L.scene_create()
+    o = L.scene_get_options(scene).contents
+    o.samples_per_pixel = 9
+    assert L.scene_get_options(scene).contents.samples_per_pixel == 9
+    assert L.scene_count_objects(scene) == 0
+    L.scene_add_object(scene, 2)
+    assert L.scene_count_objects(scene) == 1
+    L.scene_clear(scene)
+    assert L.scene_count_objects(scene) == 0
+    L.scene_destroy(scene)
+
+
+def test_texture_api_matches_oracle(H, L, orc_lib):
+    r = H.rng(3)
+    data8 = r.randint(0, 256, size=(5, 4, 3)).astype(np.uint8)
+    dataf = r.uniform(0, 2, size=(5, 4, 3)).astype(np.float32)
+    for lib in (L, orc_lib):
+        lib._tex = []
+    outs = []
+    for lib in (L, orc_lib):
+        res = []
+        for depth, data, init in ((1, data8, lib.texture_init), (4, dataf, lib.texture_init_hdr)):
+            for addr in (api.kTerraAcceleratorBVH, 1, 2):
+                for flt in (0, 1):
+                    t = api.TerraTexture()
+                    init(C.byref(t), 4, 5, 3, data.ctypes.data)
+                    t.address_mode = addr; t.filter = flt
+                    lib.texture_finalize(C.byref(t))
+                    for (u, v) in [(0.0, 0.0), (1.5, 2.25), (3.9, 4.9), (2.0, 1.0)]:
+                        uv = api.TerraFloat2(u, v)
+                        res.append(lib.texture_sample(C.byref(t), C.byref(uv), None).tuple())
+                    res.append(lib.texture_read(C.byref(t), 3, 4).tuple())
+                    dirv = api.TerraFloat3(0.3, 0.5, -0.8)
+                    res.append(lib.texture_sample_latlong(C.byref(t), C.byref(dirv), None).tuple())
+                    lib.texture_destroy(C.byref(t))
+        outs.append(np.array(res, np.float32))
+    assert np.array_equal(H.bits(outs[0]), H.bits(outs[1]))
+
+
+def test_shard_helpers(L):
+    # 1080p in 128-px tiles: 15 x 9 = 135 tiles
+    counts = [L.shard_tile_count(1920, 1080, 128, r, 8) for r in range(8)]
+    assert sum(counts) == 135 and max(counts) - min(counts) <= 1
+    assert counts == [len(runtime.shard_tiles(1920, 1080, 128, r, 8)) for r in range(8)]
+    assert L.shard_packed_bytes(1920, 1080, 128, 8) == counts[0] * 128 * 128 * 28
+    assert runtime.packed_floats_per_rank(1920, 1080, 128, 8) * 4 == L.shard_packed_bytes(1920, 1080, 128, 8)
+    assert L.shard_tile_count(64, 64, 0, 0, 1) < 0
