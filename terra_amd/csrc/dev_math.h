@@ -61,6 +61,28 @@ TDM_FN float tdm_sincosf ( float y, int shift ) {
     double sgn = ( q == 1 || q == 2 ) ? -1.0 : 1.0;
     return tdm_sincos_poly ( x * sgn, x * x, m, ( m & 2 ) != 0 );
 }
+// sin and cos of one argument with ONE range reduction; each result is bit-identical to
+// tdm_sincosf(y, 0/1) because the reduced argument and both polynomials are evaluated with
+// the same operations in the same order.
+TDM_FN void tdm_sincosf_pair ( float y, float& s, float& c ) {
+    double x = y;
+    if ( tdm_top12 ( y ) < tdm_top12 ( 0x1.921FB6p-1f ) ) {
+        if ( tdm_top12 ( y ) < tdm_top12 ( 0x1p-12f ) ) { s = y; c = 1.0f; return; }
+        double x2 = x * x;
+        s = tdm_sincos_poly ( x, x2, 0, false );
+        c = tdm_sincos_poly ( x, x2, 1, false );
+        return;
+    }
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ( ( int32_t ) r + 0x800000 ) >> 24;
+    x = x - ( double ) n * 0x1.921FB54442D18p0;
+    double x2 = x * x;
+    int qs = n & 3, m = n + 1, qc = m & 3;
+    double sgn_s = ( qs == 1 || qs == 2 ) ? -1.0 : 1.0;
+    double sgn_c = ( qc == 1 || qc == 2 ) ? -1.0 : 1.0;
+    s = tdm_sincos_poly ( x * sgn_s, x2, n, ( n & 2 ) != 0 );
+    c = tdm_sincos_poly ( x * sgn_c, x2, m, ( m & 2 ) != 0 );
+}
 TDM_FN float tdm_sinf ( float y ) { return tdm_sincosf ( y, 0 ); }
 TDM_FN float tdm_cosf ( float y ) { return tdm_sincosf ( y, 1 ); }
 

@@ -31,12 +31,38 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t
     }
 }
 
-template <int INTEGRATOR, bool COUNT>
-__global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams p ) {
-    extern __shared__ int lds_stack[];
+// Builds the block's Tracer: carves the dynamic LDS, stages the scene prefix the host
+// planned (DevRenderParams.lds_*), and leaves every thread with its own stack / leaf
+// list column. Called by all 256 threads (it contains the block barrier).
+TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t lds_nodes, uint32_t lds_tris ) {
     const int tid = threadIdx.x;
-    int* stack = lds_stack + tid;
-    const int stride = 256;
+    Tracer T;
+    T.sc = sc;
+    int* words = reinterpret_cast<int*> ( lds );
+    T.stack = words + tid;
+    T.leaves = words + stack_depth * 256 + tid;
+    T.stride = 256;
+    float4* stage = lds + ( stack_depth + TERRA_LEAF_CAP ) * 64;
+    float4* ln = stage;
+    float4* lt = ln + 4 * lds_nodes;
+    float4* lp = lt + 3 * lds_tris;
+    const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
+    const float4* gt = reinterpret_cast<const float4*> ( sc.tris );
+    const float4* gp = reinterpret_cast<const float4*> ( sc.props );
+    for ( uint32_t i = tid; i < 4 * lds_nodes; i += 256 ) ln[i] = gn[i];
+    for ( uint32_t i = tid; i < 3 * lds_tris; i += 256 ) lt[i] = gt[i];
+    for ( uint32_t i = tid; i < 4 * lds_tris; i += 256 ) lp[i] = gp[i];
+    T.l_nodes = ln; T.l_tris = reinterpret_cast<const float*> ( lt ); T.l_props = lp;
+    T.lds_nodes = lds_nodes; T.lds_tris = lds_tris;
+    __syncthreads();
+    return T;
+}
+
+template <int INTEGRATOR, bool COUNT, int MODE>
+__global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams p ) {
+    extern __shared__ float4 lds_f4[];
+    const int tid = threadIdx.x;
+    const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.lds_nodes, p.lds_tris );
 
     // block -> (own tile, 16x16 block in tile) -> pixel
     const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
@@ -74,11 +100,11 @@ __global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams 
             if ( COUNT ) ++c.samples;
         }
         Surface sf;
-        RaycastResult h = scene_raycast<COUNT> ( p.scene, ray, sf, stack, stride, c );
+        RaycastResult h = scene_raycast<COUNT, MODE> ( T, ray, sf, c );
         bool end = !h.hit;
         if ( h.hit ) {
             V3 wo = neg ( ray.d );
-            Lo = Lo + integrate<INTEGRATOR, COUNT> ( p.scene, ray, sf, h.point, wo, throughput, bounce, rs.b, stack, stride, c );
+            Lo = Lo + integrate<INTEGRATOR, COUNT, MODE> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
             float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
             V3 wi = bsdf_sample ( sf, e0, e1, e2, wo );
             float pdf = sel_max ( bsdf_pdf ( sf, wi, wo ), ( float ) 1e-4 );
@@ -120,18 +146,46 @@ static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank
     return tiles > rank ? ( tiles - rank + world - 1 ) / world : 0;
 }
 
+size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t lds_nodes, uint32_t lds_tris ) {
+    return ( size_t ) ( stack_depth + TERRA_LEAF_CAP ) * 1024 + ( size_t ) lds_nodes * 64 + ( size_t ) lds_tris * ( 48 + 64 );
+}
+
+// LDS plan: the whole scene if it fits the per-block budget, else the breadth-first node
+// prefix that fits, else nothing. The budget keeps 3 blocks (12 waves) per CU resident.
+void terra_plan_lds ( DevRenderParams& p ) {
+    const size_t budget = 48 * 1024;
+    uint32_t depth = p.scene.max_stack < 1 ? 1u : ( uint32_t ) p.scene.max_stack;
+    p.stack_depth = depth;
+    size_t fixed = ( size_t ) ( depth + TERRA_LEAF_CAP ) * 1024;
+    size_t whole = ( size_t ) p.scene.n_nodes * 64 + ( size_t ) p.scene.n_tris * 112;
+    if ( fixed + whole <= budget ) { p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris; return; }
+    p.lds_tris = 0;
+    size_t room = budget > fixed ? budget - fixed : 0;
+    uint32_t k = ( uint32_t ) ( room / 64 );
+    if ( k > p.scene.n_nodes ) k = p.scene.n_nodes;
+    if ( k >= 8 ) { p.lds_mode = 2; p.lds_nodes = k; }
+    else { p.lds_mode = 0; p.lds_nodes = 0; }
+}
+
+template <int I, int MODE>
+static hipError_t launch_mode ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
+    hipLaunchKernelGGL ( ( terra_render_kernel<I, true, MODE> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
+    return hipGetLastError();
+}
 template <int I>
 static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
-    hipLaunchKernelGGL ( ( terra_render_kernel<I, true> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
-    return hipGetLastError();
+    switch ( p.lds_mode ) {
+        case 1: return launch_mode<I, 1> ( p, blocks, lds, stream );
+        case 2: return launch_mode<I, 2> ( p, blocks, lds, stream );
+        default: return launch_mode<I, 0> ( p, blocks, lds, stream );
+    }
 }
 
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {
     uint32_t bpt = p.tile_size / 16;
     uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt;
     if ( blocks == 0 ) return hipSuccess;
-    int depth = p.scene.max_stack < 1 ? 1 : p.scene.max_stack;
-    size_t lds = ( size_t ) depth * 256 * sizeof ( int );
+    size_t lds = terra_lds_bytes ( p.stack_depth, p.lds_nodes, p.lds_tris );
     switch ( p.integrator ) {
         case 0: return launch_one<0> ( p, blocks, lds, stream );
         case 1: return launch_one<1> ( p, blocks, lds, stream );

@@ -449,13 +449,23 @@ static int upload_scene ( Scene* s ) {
         lights[l].object = o; lights[l].first_tri = s->first_tri[o]; lights[l].tri_count = ( uint32_t ) s->objects[o].triangles_count; lights[l].area = s->lights[l].area;
         for ( size_t i = 0; i < s->objects[o].triangles_count; ++i ) tri_area[s->first_tri[o] + i] = triangle_area ( s->objects[o].triangles[i] );
     }
+    // Device numbering is breadth first (child 0 before child 1), so the top of the tree is the
+    // contiguous prefix the kernel stages in LDS. Traversal order depends on the tree's shape and
+    // child order only, never on node numbers, so results are unchanged.
+    std::vector<uint32_t> bfs_of ( s->nodes.size(), 0 ), order;
+    order.reserve ( s->nodes.size() );
+    order.push_back ( 0 );
+    for ( size_t head = 0; head < order.size(); ++head ) {
+        const HostNode& h = s->nodes[order[head]];
+        for ( int c = 0; c < 2; ++c ) if ( h.type[c] == -1 ) { bfs_of[ ( size_t ) h.index[c]] = ( uint32_t ) order.size(); order.push_back ( ( uint32_t ) h.index[c] ); }
+    }
     std::vector<DevNode> nodes ( s->nodes.size() );
-    for ( size_t k = 0; k < s->nodes.size(); ++k ) {
-        const HostNode& h = s->nodes[k]; DevNode& d = nodes[k];
+    for ( size_t k = 0; k < order.size(); ++k ) {
+        const HostNode& h = s->nodes[order[k]]; DevNode& d = nodes[k];
         memcpy ( d.min0, &h.aabb[0].min, 12 ); memcpy ( d.max0, &h.aabb[0].max, 12 );
         memcpy ( d.min1, &h.aabb[1].min, 12 ); memcpy ( d.max1, &h.aabb[1].max, 12 );
         for ( int c = 0; c < 2; ++c ) {
-            if ( h.type[c] == -1 ) { d.child[c] = ( uint32_t ) h.index[c]; d.prim[c] = 0; }
+            if ( h.type[c] == -1 ) { d.child[c] = bfs_of[ ( size_t ) h.index[c]]; d.prim[c] = 0; }
             else if ( h.type[c] == 1 ) {
                 uint32_t obj = ( uint32_t ) h.index[c] & 0xffu, tri = ( uint32_t ) h.index[c] >> 8;
                 d.child[c] = DEV_CHILD_LEAF | ( s->first_tri[obj] + tri ); d.prim[c] = ( uint32_t ) h.index[c];
@@ -599,6 +609,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
         return fail ( kTerraAmdErrBadArgument, "integrator %d needs at least one emissive object (the reference asserts, src/Terra.c:1617)", p.integrator );
     p.frame_seed = s->frame_seed;
     p.counters = s->d_counters;
+    terra_plan_lds ( p );
     return 0;
 }
 

@@ -177,69 +177,189 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 }
 
 // -----------------------------------------------------------------------------
-// BVH traversal. `stack` points at this lane's column of the LDS stack,
-// consecutive entries are `stride` ints apart (bank-conflict-free per wave).
-// Order of events per popped node matches the reference: child 0 before child 1
-// both for pushes and for leaf tests; a leaf replaces the closest hit only if
-// strictly closer, so ties keep the earlier leaf.
+// Tracer: where a thread finds the scene and its traversal scratch.
+//
+// LDS layout of a block (DESIGN.md "LDS"): [node stack: stack_depth x 256 ints]
+// [leaf list: TERRA_LEAF_CAP x 256 ints] [staged nodes: lds_nodes x 64 B]
+// [staged triangles: lds_tris x 48 B] [staged vertex properties: lds_tris x 64 B].
+// Stack and leaf list are indexed [entry][thread] so the 64 lanes of a wave touch
+// 64 consecutive words (conflict free). Device node numbering is breadth first, so
+// the staged prefix [0, lds_nodes) is the top of the tree; triangles are staged only
+// when the whole soup fits.
 // -----------------------------------------------------------------------------
-struct Closest { float depth; V3 point; uint32_t tri; uint32_t prim; bool found; };
+#define TERRA_LEAF_CAP 8
 
-template <bool COUNT>
-TD Closest bvh_traverse ( const DevScene& sc, const Ray& r, const RayState& st, int* stack, int stride, Counters& c ) {
-    Closest best; best.depth = FLT_MAX; best.point = v3 ( FLT_MAX, FLT_MAX, FLT_MAX ); best.tri = 0; best.prim = 0; best.found = false;
-    int top = 1;
-    stack[0] = 0;
-    const float4* nodes = reinterpret_cast<const float4*> ( sc.nodes );
-    const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
-    while ( top > 0 ) {
-        int ni = stack[ ( --top ) * stride];
-        float4 q0 = nodes[4 * ni + 0], q1 = nodes[4 * ni + 1], q2 = nodes[4 * ni + 2], q3 = nodes[4 * ni + 3];
-        uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
-        if ( COUNT ) ++c.nodes;
-        bool inner0 = ( child0 & DEV_CHILD_LEAF ) == 0, inner1 = ( child1 & DEV_CHILD_LEAF ) == 0;
-        if ( inner0 ) {
-            if ( COUNT ) ++c.box_tests;
-            if ( ray_aabb ( r, v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), nullptr, nullptr ) ) { stack[top * stride] = ( int ) child0; ++top; }
-        }
-        if ( inner1 ) {
-            if ( COUNT ) ++c.box_tests;
-            if ( ray_aabb ( r, v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), nullptr, nullptr ) ) { stack[top * stride] = ( int ) child1; ++top; }
-        }
-        #pragma unroll
-        for ( int i = 0; i < 2; ++i ) {
-            uint32_t ch = i == 0 ? child0 : child1;
-            if ( ( ch & DEV_CHILD_LEAF ) && ch != DEV_CHILD_EMPTY ) {
-                uint32_t ti = ch & 0x7fffffffu;
-                float4 a = tris[3 * ti + 0], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
-                if ( COUNT ) ++c.tri_tests;
-                TriHit h;
-                if ( watertight ( r, st, v3 ( a.x, a.y, a.z ), v3 ( b.x, b.y, b.z ), v3 ( cc.x, cc.y, cc.z ), h ) && h.depth < best.depth ) {
-                    best.depth = h.depth; best.point = h.point; best.tri = ti;
-                    best.prim = __float_as_uint ( i == 0 ? q3.z : q3.w );
-                    best.found = true;
-                }
-            }
-        }
+struct Tracer {
+    DevScene      sc;
+    const float4* l_nodes;     // LDS copies (valid for index < lds_nodes / lds_tris)
+    const float*  l_tris;
+    const float4* l_props;
+    uint32_t      lds_nodes, lds_tris;
+    int*          stack;       // this thread's column
+    int*          leaves;
+    int           stride;      // 256
+};
+
+// -----------------------------------------------------------------------------
+// slab test of one child box. FAST is legal when every component of the ray's
+// inverse direction is finite and non-zero: then no NaN can appear (boxes and
+// origins are finite) and "a<b?a:b" differs from v_min_f32 only in the sign of a
+// zero, which the final comparison cannot see. Otherwise the compare-select form of
+// the reference runs (NaN order matters there).
+// -----------------------------------------------------------------------------
+template <bool FAST>
+TD bool slab ( V3 bmin, V3 bmax, const Ray& r ) {
+    float t1x = ( bmin.x - r.o.x ) * r.inv.x, t2x = ( bmax.x - r.o.x ) * r.inv.x;
+    float t1y = ( bmin.y - r.o.y ) * r.inv.y, t2y = ( bmax.y - r.o.y ) * r.inv.y;
+    float t1z = ( bmin.z - r.o.z ) * r.inv.z, t2z = ( bmax.z - r.o.z ) * r.inv.z;
+    if ( FAST ) {
+        float tmin = __builtin_fmaxf ( __builtin_fmaxf ( __builtin_fminf ( t1x, t2x ), __builtin_fminf ( t1y, t2y ) ), __builtin_fminf ( t1z, t2z ) );
+        float tmax = __builtin_fminf ( __builtin_fminf ( __builtin_fmaxf ( t1x, t2x ), __builtin_fmaxf ( t1y, t2y ) ), __builtin_fmaxf ( t1z, t2z ) );
+        return tmax > __builtin_fmaxf ( tmin, 0.f );
     }
+    float tmin = sel_min ( t1x, t2x ), tmax = sel_max ( t1x, t2x );
+    tmin = sel_max ( tmin, sel_min ( t1y, t2y ) ); tmax = sel_min ( tmax, sel_max ( t1y, t2y ) );
+    tmin = sel_max ( tmin, sel_min ( t1z, t2z ) ); tmax = sel_min ( tmax, sel_max ( t1z, t2z ) );
+    return tmax > sel_max ( tmin, 0.f );
+}
+
+TD bool ray_is_regular ( const Ray& r ) {
+    // finite and non-zero inverse direction components
+    uint32_t ax = tdm_bits ( r.inv.x ) & 0x7fffffffu, ay = tdm_bits ( r.inv.y ) & 0x7fffffffu, az = tdm_bits ( r.inv.z ) & 0x7fffffffu;
+    return ax - 1u < 0x7f7fffffu && ay - 1u < 0x7f7fffffu && az - 1u < 0x7f7fffffu;
+}
+
+// -----------------------------------------------------------------------------
+// watertight test on components already gathered in the ray's permuted axes:
+// p?[0..2] = vertex[ix], vertex[iy], vertex[iz]; o = origin permuted the same way.
+// Same operations, in the same order, as watertight() above.
+// -----------------------------------------------------------------------------
+TD bool watertight_permuted ( const float pa[3], const float pb[3], const float pc[3], V3 o, const RayState& s, float& depth_out ) {
+    float Aix = pa[0] - o.x, Aiy = pa[1] - o.y, Aiz = pa[2] - o.z;
+    float Bix = pb[0] - o.x, Biy = pb[1] - o.y, Biz = pb[2] - o.z;
+    float Cix = pc[0] - o.x, Ciy = pc[1] - o.y, Ciz = pc[2] - o.z;
+    float Ax = Aix - s.shearx * Aiz, Ay = Aiy - s.sheary * Aiz;
+    float Bx = Bix - s.shearx * Biz, By = Biy - s.sheary * Biz;
+    float Cx = Cix - s.shearx * Ciz, Cy = Ciy - s.sheary * Ciz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if ( U == 0.f || V == 0.f || W == 0.f ) {
+        U = ( float ) ( ( double ) Cx * ( double ) By - ( double ) Cy * ( double ) Bx );
+        V = ( float ) ( ( double ) Ax * ( double ) Cy - ( double ) Ay * ( double ) Cx );
+        W = ( float ) ( ( double ) Bx * ( double ) Ay - ( double ) By * ( double ) Ax );
+    }
+    uint32_t sign = tdm_bits ( U ) & 0x80000000u;
+    if ( ( ( tdm_bits ( V ) ^ tdm_bits ( U ) ) | ( tdm_bits ( W ) ^ tdm_bits ( U ) ) ) & 0x80000000u ) return false;
+    float det = U + V + W;
+    if ( det == 0.f ) return false;
+    float Az = s.scalez * Aiz, Bz = s.scalez * Biz, Cz = s.scalez * Ciz;
+    float depth = U * Az + V * Bz + W * Cz;
+    if ( tdm_float ( tdm_bits ( depth ) ^ sign ) < 0.f ) return false;
+    float inv_det = 1.f / det;
+    depth_out = depth * inv_det;
+    return true;
+}
+
+// -----------------------------------------------------------------------------
+// BVH traversal (reference src/TerraBVH.c:250-310), restructured without changing
+// what is computed:
+//   * the node loop only does slab tests and stack traffic; leaves met on the way are
+//     appended to a per-lane list and tested afterwards in the order they were met.
+//     The reference never lets a hit influence the traversal (no culling against the
+//     closest hit), so testing the leaves later, in the same order, with the same
+//     strict "<" on depth, selects the same triangle;
+//   * when a lane's list is full the lists are drained and the node loop resumes;
+//   * the hit point is formed once, from the winning depth (same expression).
+// MODE 0: nodes/triangles from global memory; 1: everything staged in LDS;
+// 2: staged node prefix, triangles global.
+// -----------------------------------------------------------------------------
+struct Closest { float depth; uint32_t tri; };
+
+template <bool COUNT, int MODE, bool FAST>
+TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
+    const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
+    const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
+    const int kx = st.ix, ky = st.iy, kz = st.iz;
+    int top = 1, nleaf = 0;
+    T.stack[0] = 0;
+    for ( ;; ) {
+        while ( top > 0 && nleaf <= TERRA_LEAF_CAP - 2 ) {
+            uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+            float4 q0, q1, q2, q3;
+            if ( MODE == 1 || ( MODE == 2 && ni < T.lds_nodes ) ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
+            else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
+            uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+            if ( COUNT ) ++c.nodes;
+            bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
+            bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
+            bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
+            if ( COUNT ) c.box_tests += ( leaf0 ? 0u : 1u ) + ( leaf1 ? 0u : 1u );
+            if ( !leaf0 && hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
+            if ( !leaf1 && hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
+            if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child0 & 0x7fffffffu ); ++nleaf; }
+            if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child1 & 0x7fffffffu ); ++nleaf; }
+        }
+        for ( int i = 0; i < nleaf; ++i ) {
+            uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
+            float pa[3], pb[3], pc[3];
+            if ( MODE == 1 ) {
+                const float* t = T.l_tris + 12 * ti;
+                pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
+                pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
+                pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
+            } else {
+                float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
+                V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+                pa[0] = pick ( va, kx ); pa[1] = pick ( va, ky ); pa[2] = pick ( va, kz );
+                pb[0] = pick ( vb, kx ); pb[1] = pick ( vb, ky ); pb[2] = pick ( vb, kz );
+                pc[0] = pick ( vc, kx ); pc[1] = pick ( vc, ky ); pc[2] = pick ( vc, kz );
+            }
+            if ( COUNT ) ++c.tri_tests;
+            float depth;
+            if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
+        }
+        nleaf = 0;
+        if ( top <= 0 ) break;
+    }
+}
+
+template <bool COUNT, int MODE>
+TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
+    Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
+    V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+    // the slab variant is chosen per WAVE: one irregular ray sends its whole wave down the exact path
+    if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true> ( T, r, st, o_perm, best, c );
+    else traverse_loops<COUNT, MODE, false> ( T, r, st, o_perm, best, c );
     return best;
 }
 
 // -----------------------------------------------------------------------------
 // surface
 // -----------------------------------------------------------------------------
+// The reference also stores the tangent frame (terra_f4x4_basis of the normal) in the
+// surface; it is a pure function of the normal, so it is rebuilt where it is consumed
+// (diffuse sampling) instead of being carried in 9 registers.
 struct Surface {
     V3    normal;
     V3    emissive;
     V3    attr[4];      // the presets use at most 4 slots (Phong); slot 3.x is Phong's sample-pick scratch
-    Basis basis;
     int   bsdf;
 };
 
-TD void surface_init ( const DevScene& sc, uint32_t ti, V3 point, Surface& sf, uint32_t& object_out, uint32_t& tri_in_object_out, uint32_t& nattr_out ) {
-    const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
-    const float4* props = reinterpret_cast<const float4*> ( sc.props );
-    float4 t0 = tris[3 * ti + 0], t1 = tris[3 * ti + 1], t2 = tris[3 * ti + 2];
+template <int MODE>
+TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint32_t& object_out, uint32_t& tri_in_object_out, uint32_t& nattr_out ) {
+    float4 t0, t1, t2, p0, p1, p2;
+    if ( MODE == 1 ) {
+        const float4* lt = reinterpret_cast<const float4*> ( T.l_tris );
+        t0 = lt[3 * ti]; t1 = lt[3 * ti + 1]; t2 = lt[3 * ti + 2];
+        p0 = T.l_props[4 * ti]; p1 = T.l_props[4 * ti + 1]; p2 = T.l_props[4 * ti + 2];
+    } else {
+        const float4* tris = reinterpret_cast<const float4*> ( T.sc.tris );
+        const float4* props = reinterpret_cast<const float4*> ( T.sc.props );
+        t0 = tris[3 * ti]; t1 = tris[3 * ti + 1]; t2 = tris[3 * ti + 2];
+        p0 = props[4 * ti]; p1 = props[4 * ti + 1]; p2 = props[4 * ti + 2];
+    }
     V3 ta = v3 ( t0.x, t0.y, t0.z ), tb = v3 ( t1.x, t1.y, t1.z ), tc = v3 ( t2.x, t2.y, t2.z );
     uint32_t object = __float_as_uint ( t0.w );
     object_out = object; tri_in_object_out = __float_as_uint ( t1.w );
@@ -250,32 +370,31 @@ TD void surface_init ( const DevScene& sc, uint32_t ti, V3 point, Surface& sf, u
     float u = ( d11 * dp0 - d01 * dp1 ) / div;
     float v = ( d00 * dp1 - d01 * dp0 ) / div;
     float w = 1 - u - v;
-    float4 p0 = props[4 * ti + 0], p1 = props[4 * ti + 1], p2 = props[4 * ti + 2];
     V3 na = v3 ( p0.x, p0.y, p0.z ), nb = v3 ( p0.w, p1.x, p1.y ), nc = v3 ( p1.z, p1.w, p2.x );
     sf.normal = normalize ( ( nc * v + nb * u ) + na * w );
     // texcoords are only consumed by textured attributes (not on the device yet): constants ignore them
-    const DevMaterial& m = sc.mats[object];
+    const DevMaterial& m = T.sc.mats[object];
     sf.emissive = v3p ( m.emissive );
     #pragma unroll
     for ( int i = 0; i < 4; ++i ) sf.attr[i] = v3p ( m.attributes[i] );
     sf.bsdf = m.bsdf;
     nattr_out = m.attributes_count;
-    sf.basis = make_basis ( sf.normal );
 }
 
 struct RaycastResult { bool hit; uint32_t object, tri_in_object, tri; V3 point; };
 
-template <bool COUNT>
-TD RaycastResult scene_raycast ( const DevScene& sc, const Ray& in, Surface& sf, int* stack, int stride, Counters& c ) {
+template <bool COUNT, int MODE>
+TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Counters& c ) {
     Ray r = in;
     r.o = r.o + r.d * 0.001f;
     RayState st = ray_state_init ( r );
     if ( COUNT ) ++c.rays;
-    Closest best = bvh_traverse<COUNT> ( sc, r, st, stack, stride, c );
-    RaycastResult res; res.hit = best.found; res.point = best.point; res.tri = best.tri; res.object = 0; res.tri_in_object = 0;
-    if ( best.found ) {
+    Closest best = bvh_traverse<COUNT, MODE> ( T, r, st, c );
+    RaycastResult res; res.hit = best.tri != 0xffffffffu; res.tri = best.tri; res.object = 0; res.tri_in_object = 0;
+    res.point = res.hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
+    if ( res.hit ) {
         uint32_t nattr;
-        surface_init ( sc, best.tri, best.point, sf, res.object, res.tri_in_object, nattr );
+        surface_init<MODE> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
         if ( COUNT ) { ++c.hits; c.attr_fetches += nattr + 1; }
     }
     return res;
@@ -294,10 +413,12 @@ TD Ray surface_ray ( const Surface& sf, V3 p, V3 d, float sign ) {
 TD V3 diffuse_sample ( const Surface& sf, float e1, float e2 ) {
     float r = sqrtf ( e1 );
     float theta = 2 * TERRA_PI_F * e2;
-    float x = r * tdm_cosf ( theta );
-    float z = r * tdm_sinf ( theta );
+    float sn, cs;
+    tdm_sincosf_pair ( theta, sn, cs );
+    float x = r * cs;
+    float z = r * sn;
     V3 wi = v3 ( x, sqrtf ( sel_max ( 0.f, 1 - e1 ) ), z );
-    return normalize ( basis_apply ( sf.basis, wi ) );
+    return normalize ( basis_apply ( make_basis ( sf.normal ), wi ) );
 }
 TD float diffuse_pdf ( const Surface& sf, V3 wi ) { return sel_max ( 0.f, dot ( sf.normal, wi ) ) / TERRA_PI_F; }
 TD V3 diffuse_eval ( const Surface& sf ) { return sf.attr[0] * ( float ) ( 1. / ( double ) TERRA_PI_F ); }
@@ -388,8 +509,9 @@ TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c ) 
     return ls;
 }
 
-template <bool COUNT>
-TD V3 integrate_direct ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, int* stack, int stride, Counters& c ) {
+template <bool COUNT, int MODE>
+TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
+    const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
     if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
     LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
@@ -397,7 +519,7 @@ TD V3 integrate_direct ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throug
     V3 wi = normalize ( p_to_light );
     Surface lsf;
     Ray r = surface_ray ( sf, p, wi, 1.f );
-    RaycastResult h = scene_raycast<COUNT> ( sc, r, lsf, stack, stride, c );
+    RaycastResult h = scene_raycast<COUNT, MODE> ( T, r, lsf, c );
     if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
         float cosv = dot ( neg ( wi ), ls.norm );
         if ( cosv > 0 ) {
@@ -411,8 +533,9 @@ TD V3 integrate_direct ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throug
     return had ( Lo, throughput );
 }
 
-template <bool COUNT, bool DEBUG_WEIGHTS>
-TD V3 integrate_mis ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, int* stack, int stride, Counters& c ) {
+template <bool COUNT, int MODE, bool DEBUG_WEIGHTS>
+TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
+    const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
     if ( DEBUG_WEIGHTS ) { if ( bounce != 0 ) return Lo; }
     else if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
@@ -424,7 +547,7 @@ TD V3 integrate_mis ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throughpu
         V3 wi = normalize ( p_to_light );
         Surface lsf;
         Ray r = surface_ray ( sf, p, wi, 1.f );
-        RaycastResult h = scene_raycast<COUNT> ( sc, r, lsf, stack, stride, c );
+        RaycastResult h = scene_raycast<COUNT, MODE> ( T, r, lsf, c );
         if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
             float cosv = dot ( ls.norm, neg ( wi ) );
             if ( cosv > 0 ) {
@@ -452,7 +575,7 @@ TD V3 integrate_mis ( const DevScene& sc, Surface& sf, V3 p, V3 wo, V3 throughpu
         V3 light_wo = neg ( wi );
         Surface lsf;
         Ray r = surface_ray ( sf, p, wi, 1.f );
-        RaycastResult h = scene_raycast<COUNT> ( sc, r, lsf, stack, stride, c );
+        RaycastResult h = scene_raycast<COUNT, MODE> ( T, r, lsf, c );
         if ( h.hit && h.object == ls.light_object ) {
             float NoW = dot ( lsf.normal, light_wo );
             if ( NoW > 0 ) {
@@ -493,15 +616,15 @@ TD V3 integrate_debug_normals ( const Surface& sf, uint32_t bounce ) {
 }
 
 // integrator ids = TerraIntegrator (reference include/Terra.h:149-157)
-template <int INTEGRATOR, bool COUNT>
-TD V3 integrate ( const DevScene& sc, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, int* stack, int stride, Counters& c ) {
+template <int INTEGRATOR, bool COUNT, int MODE>
+TD V3 integrate ( const Tracer& T, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     if ( INTEGRATOR == 0 ) {
         if ( dot ( wo, sf.normal ) > 0 ) return had ( sf.emissive, throughput );
         return v3 ( 0, 0, 0 );
     } else if ( INTEGRATOR == 1 ) {
-        return integrate_direct<COUNT> ( sc, sf, p, wo, throughput, bounce, rb, stack, stride, c );
+        return integrate_direct<COUNT, MODE> ( T, sf, p, wo, throughput, bounce, rb, c );
     } else if ( INTEGRATOR == 2 ) {
-        return integrate_mis<COUNT, false> ( sc, sf, p, wo, throughput, bounce, rb, stack, stride, c );
+        return integrate_mis<COUNT, MODE, false> ( T, sf, p, wo, throughput, bounce, rb, c );
     } else if ( INTEGRATOR == 3 ) {
         return bounce != 0 ? v3 ( 0, 0, 0 ) : v3 ( 1, 1, 1 );
     } else if ( INTEGRATOR == 4 ) {
@@ -511,7 +634,7 @@ TD V3 integrate ( const DevScene& sc, const Ray& ray, Surface& sf, V3 p, V3 wo, 
     } else if ( INTEGRATOR == 5 ) {
         return integrate_debug_normals ( sf, bounce );
     } else {
-        return integrate_mis<COUNT, true> ( sc, sf, p, wo, throughput, bounce, rb, stack, stride, c );
+        return integrate_mis<COUNT, MODE, true> ( T, sf, p, wo, throughput, bounce, rb, c );
     }
 }
 
@@ -519,15 +642,15 @@ TD V3 integrate ( const DevScene& sc, const Ray& ray, Surface& sf, V3 p, V3 wo, 
 // one full path (the reference's terra_trace), used by the unit entry point and,
 // restructured with path regeneration, by the render kernel
 // -----------------------------------------------------------------------------
-template <int INTEGRATOR, bool COUNT>
-TD V3 trace_path ( const DevScene& sc, Ray ray, uint32_t bounces, Pcg32& rb, int* stack, int stride, Counters& c ) {
+template <int INTEGRATOR, bool COUNT, int MODE>
+TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counters& c ) {
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     for ( uint32_t bounce = 0; bounce <= bounces; ++bounce ) {
         Surface sf;
-        RaycastResult h = scene_raycast<COUNT> ( sc, ray, sf, stack, stride, c );
+        RaycastResult h = scene_raycast<COUNT, MODE> ( T, ray, sf, c );
         if ( !h.hit ) break;
         V3 wo = neg ( ray.d );
-        Lo = Lo + integrate<INTEGRATOR, COUNT> ( sc, ray, sf, h.point, wo, throughput, bounce, rb, stack, stride, c );
+        Lo = Lo + integrate<INTEGRATOR, COUNT, MODE> ( T, ray, sf, h.point, wo, throughput, bounce, rb, c );
         float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
         V3 wi = bsdf_sample ( sf, e0, e1, e2, wo );
         float pdf = sel_max ( bsdf_pdf ( sf, wi, wo ), ( float ) 1e-4 );

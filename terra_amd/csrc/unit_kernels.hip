@@ -74,6 +74,12 @@ hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, c
     return hipGetLastError();
 }
 
+// unit kernels read the scene from global memory (MODE 0); LDS only holds stack + leaf list
+__device__ __forceinline__ Tracer unit_tracer ( const DevScene& sc, int* lds ) {
+    Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.lds_nodes = 0; T.lds_tris = 0;
+    T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.stride = 256;
+    return T;
+}
 __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
     extern __shared__ int lds_stack[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,21 +87,25 @@ __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, c
     Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
     RayState s = ray_state_init ( r );
     Counters c = counters_zero();
-    Closest b = bvh_traverse<false> ( sc, r, s, lds_stack + threadIdx.x, 256, c );
-    found[i] = b.found ? 1 : 0;
-    prim[i] = b.found ? b.prim : 0u;
-    point[3 * i] = b.point.x; point[3 * i + 1] = b.point.y; point[3 * i + 2] = b.point.z;
+    Tracer T = unit_tracer ( sc, lds_stack );
+    Closest b = bvh_traverse<false, 0> ( T, r, s, c );
+    bool f = b.tri != 0xffffffffu;
+    found[i] = f ? 1 : 0;
+    prim[i] = f ? ( sc.tris[b.tri].object | ( sc.tris[b.tri].tri_in_object << 8 ) ) : 0u;
+    V3 pt = f ? r.o + r.d * b.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
+    point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
 }
-static size_t stack_lds ( const DevScene& sc ) { return ( size_t ) ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 * sizeof ( int ); }
+static size_t stack_lds ( const DevScene& sc ) { return ( size_t ) ( ( sc.max_stack < 1 ? 1 : sc.max_stack ) + TERRA_LEAF_CAP ) * 256 * sizeof ( int ); }
 hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
     hipLaunchKernelGGL ( k_bvh_traverse, UNIT_GRID ( n ), stack_lds ( sc ), 0, sc, n, o, d, found, prim, point );
     return hipGetLastError();
 }
 
 __device__ void surface_to_floats ( const DevScene& sc, const Surface& sf, uint32_t object, float* q ) {
-    q[0] = sf.basis.r0[0]; q[1] = sf.basis.r0[1]; q[2] = sf.basis.r0[2]; q[3] = 0.f;
-    q[4] = sf.basis.r1[0]; q[5] = sf.basis.r1[1]; q[6] = sf.basis.r1[2]; q[7] = 0.f;
-    q[8] = sf.basis.r2[0]; q[9] = sf.basis.r2[1]; q[10] = sf.basis.r2[2]; q[11] = 0.f;
+    Basis bs = make_basis ( sf.normal );
+    q[0] = bs.r0[0]; q[1] = bs.r0[1]; q[2] = bs.r0[2]; q[3] = 0.f;
+    q[4] = bs.r1[0]; q[5] = bs.r1[1]; q[6] = bs.r1[2]; q[7] = 0.f;
+    q[8] = bs.r2[0]; q[9] = bs.r2[1]; q[10] = bs.r2[2]; q[11] = 0.f;
     q[12] = 0.f; q[13] = 0.f; q[14] = 0.f; q[15] = 1.f;
     q[16] = sf.normal.x; q[17] = sf.normal.y; q[18] = sf.normal.z;
     q[19] = sf.emissive.x; q[20] = sf.emissive.y; q[21] = sf.emissive.z;
@@ -109,7 +119,8 @@ __global__ __launch_bounds__ ( 256 ) void k_raycast ( DevScene sc, int n, const 
     Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
     Counters c = counters_zero();
     Surface sf;
-    RaycastResult h = scene_raycast<false> ( sc, r, sf, lds_stack + threadIdx.x, 256, c );
+    Tracer T = unit_tracer ( sc, lds_stack );
+    RaycastResult h = scene_raycast<false, 0> ( T, r, sf, c );
     obj[i] = h.hit ? ( int ) h.object : -1;
     tri[i] = h.hit ? ( int ) h.tri_in_object : 0;
     point[3 * i] = h.point.x; point[3 * i + 1] = h.point.y; point[3 * i + 2] = h.point.z;
@@ -130,7 +141,8 @@ __global__ __launch_bounds__ ( 256 ) void k_trace ( DevScene sc, uint32_t bounce
     Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
     Pcg32 b; b.state = stateB[i]; b.inc = incB[i];
     Counters c = counters_zero();
-    V3 L = trace_path<I, true> ( sc, r, bounces, b, lds_stack + threadIdx.x, 256, c );
+    Tracer T = unit_tracer ( sc, lds_stack );
+    V3 L = trace_path<I, true, 0> ( T, r, bounces, b, c );
     radiance[3 * i] = L.x; radiance[3 * i + 1] = L.y; radiance[3 * i + 2] = L.z;
     rand_calls[i] = c.rand_calls;
 }
@@ -150,9 +162,7 @@ __global__ void k_bsdf ( int kind, int n, float* surfaces47, const float* e3, co
     if ( i >= n ) return;
     float* q = surfaces47 + 47 * ( size_t ) i;
     Surface sf;
-    sf.basis.r0[0] = q[0]; sf.basis.r0[1] = q[1]; sf.basis.r0[2] = q[2];
-    sf.basis.r1[0] = q[4]; sf.basis.r1[1] = q[5]; sf.basis.r1[2] = q[6];
-    sf.basis.r2[0] = q[8]; sf.basis.r2[1] = q[9]; sf.basis.r2[2] = q[10];
+    // the tangent frame is a function of the normal (terra_f4x4_basis); q[0..15] is not read
     sf.normal = v3p ( q + 16 ); sf.emissive = v3p ( q + 19 );
     for ( int a = 0; a < 4; ++a ) sf.attr[a] = v3p ( q + 23 + 3 * a );
     sf.bsdf = kind;
