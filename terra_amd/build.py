@@ -35,9 +35,12 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
-    objdir = HERE / "build"
+def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: str = "") -> Path:
+    """variant != "": an experiment build (extra_flags, e.g. -DTERRA_LEAF_CAP=4) written to libterra_amd_<variant>.so;
+    select it at run time with TERRA_AMD_LIB=<path> (terra_amd/runtime.py)."""
+    objdir = HERE / ("build" + ("_" + variant if variant else ""))
     objdir.mkdir(exist_ok=True)
+    OUT = HERE / (f"libterra_amd_{variant}.so" if variant else "libterra_amd.so")
     deps_common = [CSRC / h for h in HEADERS] + [HERE.parent / "include" / h for h in ("Terra.h", "TerraMath.h", "TerraPresets.h", "terra_amd.h")] + [Path(__file__)]
     jobs = []
     for src in SOURCES:
@@ -72,5 +75,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True)
+    # python -m terra_amd.build [--force] [--variant NAME -DFOO=1 ...]
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = ""
+    if "--variant" in args:
+        i = args.index("--variant"); variant = args[i + 1]; del args[i:i + 2]
+    p = build(force="--force" in sys.argv, verbose=True, extra_flags=tuple(args), variant=variant)
     print(p)

@@ -20,14 +20,15 @@
 
 struct DevResult { float acc[3]; int samples; };
 
-TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t pixels ) {
-    uint32_t v[9] = { c.rays, c.nodes, c.box_tests, c.tri_tests, c.hits, c.samples, c.rand_calls, c.attr_fetches, pixels };
+TD void wave_flush_counters ( const Counters& c, unsigned long long* g ) {
+    const uint32_t v[6] = { c.rays, c.nodes, c.tri_tests, c.hits, c.rand_calls, c.attr_fetches };
+    const int slot[6] = { kCtrRays, kCtrNodes, kCtrTriTests, kCtrHits, kCtrRandCalls, kCtrAttrFetches };
     #pragma unroll
-    for ( int k = 0; k < 9; ++k ) {
+    for ( int k = 0; k < 6; ++k ) {
         unsigned long long x = v[k];
         #pragma unroll
         for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
-        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &g[k], x );
+        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &g[slot[k]], x );
     }
 }
 
@@ -58,8 +59,18 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     return T;
 }
 
+// Occupancy target per integrator (second __launch_bounds__ argument = waves per SIMD = 256-thread
+// blocks per CU). Measured on MI355X (profiles/): the Simple/debug kernels run fastest at 5 even
+// with a small spill; Direct/MIS carry a second surface and more live state.
+#ifndef TERRA_WAVES_SIMPLE
+#define TERRA_WAVES_SIMPLE 5
+#endif
+#ifndef TERRA_WAVES_LIGHT
+#define TERRA_WAVES_LIGHT 4
+#endif
+#define TERRA_WAVES_FOR(I) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : TERRA_WAVES_SIMPLE )
 template <int INTEGRATOR, bool COUNT, int MODE>
-__global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams p ) {
+__global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
     const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.lds_nodes, p.lds_tris );
@@ -76,13 +87,11 @@ __global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams 
     const uint32_t ly = ty * p.tile_size + by * 16 + ( wave >> 1 ) * 8 + ( lane >> 3 );
     const bool valid = lx < p.w && ly < p.h;
     const uint32_t px = p.x + lx, py = p.y + ly;
-    const size_t pix = ( size_t ) py * p.fb_w + px;
 
     DevResult* results = reinterpret_cast<DevResult*> ( p.results );
-    DevResult prior; prior.acc[0] = prior.acc[1] = prior.acc[2] = 0.f; prior.samples = 0;
-    if ( valid ) prior = results[pix];
-
-    PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) pix, ( uint64_t ) ( uint32_t ) prior.samples );
+    // only the sample count is needed up front (it keys the streams); the running sum is re-read at the end
+    const int prior_samples = valid ? results[ ( size_t ) py * p.fb_w + px].samples : 0;
+    PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples );
     Counters c = counters_zero();
 
     V3 acc = v3 ( 0, 0, 0 ), Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
@@ -97,7 +106,6 @@ __global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams 
             float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
             ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
             Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++s;
-            if ( COUNT ) ++c.samples;
         }
         Surface sf;
         RaycastResult h = scene_raycast<COUNT, MODE> ( T, ray, sf, c );
@@ -126,6 +134,8 @@ __global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams 
     }
 
     if ( valid ) {
+        const size_t pix = ( size_t ) py * p.fb_w + px;
+        const DevResult prior = results[pix];
         DevResult out;
         out.acc[0] = acc.x + prior.acc[0]; out.acc[1] = acc.y + prior.acc[1]; out.acc[2] = acc.z + prior.acc[2];
         out.samples = prior.samples + ( int ) p.spp;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_render_kernel ( DevRenderParams 
         p.pixels[3 * pix + 0] = color.x; p.pixels[3 * pix + 1] = color.y; p.pixels[3 * pix + 2] = color.z;
         if ( p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
     }
-    if ( COUNT ) wave_flush_counters ( c, p.counters, valid ? 1u : 0u );
+    if ( COUNT ) wave_flush_counters ( c, p.counters );
 }
 
 // ---- launch -------------------------------------------------------------------

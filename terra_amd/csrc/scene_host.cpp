@@ -226,7 +226,7 @@ struct Scene {
     // device replica
     DevScene dev; void* d_blob = nullptr; size_t d_bytes = 0;
     unsigned long long* d_counters = nullptr;
-    uint64_t launches = 0;
+    uint64_t launches = 0, stat_pixels = 0, stat_samples = 0;
     std::string commit_error;
 };
 
@@ -552,8 +552,11 @@ extern "C" int terra_amd_get_stats ( HTerraScene h, TerraAmdStats* out ) {
     unsigned long long c[kCtrCount];
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( c, s->d_counters, sizeof c, hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
-    out->rays = c[kCtrRays]; out->nodes = c[kCtrNodes]; out->box_tests = c[kCtrBoxTests]; out->tri_tests = c[kCtrTriTests]; out->hits = c[kCtrHits];
-    out->samples = c[kCtrSamples]; out->rand_calls = c[kCtrRandCalls]; out->attr_fetches = c[kCtrAttrFetches]; out->pixels = c[kCtrPixels]; out->launches = s->launches;
+    out->rays = c[kCtrRays]; out->nodes = c[kCtrNodes]; out->tri_tests = c[kCtrTriTests]; out->hits = c[kCtrHits];
+    out->rand_calls = c[kCtrRandCalls]; out->attr_fetches = c[kCtrAttrFetches];
+    // derived exactly on the host (see Counters in trace_device.h)
+    out->box_tests = s->dev.n_tris >= 2 ? 2 * out->nodes - out->tri_tests : 0;
+    out->samples = s->stat_samples; out->pixels = s->stat_pixels; out->launches = s->launches;
     return 0;
 }
 extern "C" int terra_amd_reset_stats ( HTerraScene h ) {
@@ -561,7 +564,7 @@ extern "C" int terra_amd_reset_stats ( HTerraScene h ) {
     if ( !s->device_ok ) return fail ( kTerraAmdErrNotCommitted, "scene has no device replica" );
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemset ( s->d_counters, 0, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
-    s->launches = 0;
+    s->launches = 0; s->stat_pixels = 0; s->stat_samples = 0;
     return 0;
 }
 
@@ -613,6 +616,21 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     return 0;
 }
 
+// pixels a launch covers: own tiles (t % world == rank) clipped to the rectangle
+static uint64_t shard_pixels ( const DevRenderParams& p ) {
+    uint64_t n = 0;
+    const uint32_t tx = ( p.w + p.tile_size - 1 ) / p.tile_size, ty = ( p.h + p.tile_size - 1 ) / p.tile_size;
+    for ( uint32_t t = p.rank; t < tx * ty; t += p.world ) {
+        uint32_t x0 = ( t % tx ) * p.tile_size, y0 = ( t / tx ) * p.tile_size;
+        n += ( uint64_t ) std::min ( p.tile_size, p.w - x0 ) * std::min ( p.tile_size, p.h - y0 );
+    }
+    return n;
+}
+static void account_launch ( Scene* s, const DevRenderParams& p ) {
+    uint64_t px = shard_pixels ( p );
+    ++s->launches; s->stat_pixels += px; s->stat_samples += px * p.spp;
+}
+
 extern "C" int terra_amd_render_device_sharded ( const TerraCamera* cam, HTerraScene h, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h,
                                                  size_t x, size_t y, size_t w, size_t hgt, size_t tile, int rank, int world, void* d_rand_calls, void* stream ) {
     Scene* s = S ( h );
@@ -623,7 +641,7 @@ extern "C" int terra_amd_render_device_sharded ( const TerraCamera* cam, HTerraS
     p.pixels = ( float* ) d_pixels; p.results = d_results; p.rand_calls = ( uint32_t* ) d_rand_calls;
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     HIP_TRY ( terra_launch_render ( p, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
-    ++s->launches;
+    account_launch ( s, p );
     return 0;
 }
 extern "C" int terra_amd_render_device ( const TerraCamera* cam, HTerraScene h, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h,
@@ -727,7 +745,7 @@ static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffe
     HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, dres, rpitch, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, dpix, ppitch, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipStreamSynchronize ( t.stream ), kTerraAmdErrLaunch );
-    ++s->launches;
+    account_launch ( s, p );
     return 0;
 }
 

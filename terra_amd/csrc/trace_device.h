@@ -71,9 +71,12 @@ TD Ray make_ray ( V3 o, V3 d ) { Ray r; r.o = o; r.d = d; r.inv = v3 ( 1.f / d.x
 
 struct RayState { float shearx, sheary, scalez; int ix, iy, iz; };
 
-// per-lane work counters (registers); flushed with one atomic per wave and counter
-struct Counters { uint32_t rays, nodes, box_tests, tri_tests, hits, samples, rand_calls, attr_fetches; };
-TD Counters counters_zero() { Counters c; c.rays = c.nodes = c.box_tests = c.tri_tests = c.hits = c.samples = c.rand_calls = c.attr_fetches = 0; return c; }
+// per-lane work counters (registers); flushed with one atomic per wave and counter.
+// Not counted on the device because the host can derive them exactly: slab tests
+// (= 2*nodes - tri_tests: every child of a popped node is either slab-tested or, if a
+// leaf, triangle-tested), camera samples and pixels (tile geometry x spp).
+struct Counters { uint32_t rays, nodes, tri_tests, hits, rand_calls, attr_fetches; };
+TD Counters counters_zero() { Counters c; c.rays = c.nodes = c.tri_tests = c.hits = c.rand_calls = c.attr_fetches = 0; return c; }
 
 // -----------------------------------------------------------------------------
 // camera
@@ -187,7 +190,9 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 // the staged prefix [0, lds_nodes) is the top of the tree; triangles are staged only
 // when the whole soup fits.
 // -----------------------------------------------------------------------------
-#define TERRA_LEAF_CAP 8
+#ifndef TERRA_LEAF_CAP
+#define TERRA_LEAF_CAP 16
+#endif
 
 struct Tracer {
     DevScene      sc;
@@ -294,7 +299,6 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
             bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
             bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
             bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
-            if ( COUNT ) c.box_tests += ( leaf0 ? 0u : 1u ) + ( leaf1 ? 0u : 1u );
             if ( !leaf0 && hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
             if ( !leaf1 && hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
             if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child0 & 0x7fffffffu ); ++nleaf; }

@@ -18,7 +18,8 @@ import numpy as np
 from . import api, scenes
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libterra_amd.so"
+import os as _os
+LIB_PATH = Path(_os.environ.get("TERRA_AMD_LIB", HERE / "libterra_amd.so"))     # TERRA_AMD_LIB: experiment builds (terra_amd/build.py --variant)
 
 _lib: Optional[api.TerraLib] = None
 
