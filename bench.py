@@ -61,6 +61,8 @@ def workload(name: str, spp_override):
         d = scenes.cornell_box(256, 256, 4, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "cornell_1080p_512spp_direct":
         d = scenes.cornell_box(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorDirect)
+    elif name == "hall_1080p_256spp":        # BASELINE.json configs[2]: ~100k triangles, deep reference-tree traversal
+        d = scenes.sponza_hall(1920, 1080, 256, bounces=8, integrator=api.kTerraIntegratorSimple)
     else:
         raise SystemExit(f"unknown workload {name}")
     if spp_override:

@@ -109,7 +109,7 @@ struct DevRenderParams {
     unsigned long long* counters;   // kCtrCount entries
     // LDS plan of a block (host decides, kernel obeys): stack_depth stack entries per thread,
     // lds_nodes nodes (breadth-first prefix) and lds_tris triangles (+ their vertex properties)
-    // staged; lds_mode 0 = nothing staged, 1 = whole scene staged, 2 = node prefix only
-    uint32_t stack_depth, lds_nodes, lds_tris;
+    // staged; leaf_cap deferred-leaf entries per thread; lds_mode 0 = nothing staged, 1 = whole scene, 2 = node prefix only
+    uint32_t stack_depth, leaf_cap, lds_nodes, lds_tris;
     int32_t  lds_mode;
 };

@@ -35,7 +35,7 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g ) {
 // Builds the block's Tracer: carves the dynamic LDS, stages the scene prefix the host
 // planned (DevRenderParams.lds_*), and leaves every thread with its own stack / leaf
 // list column. Called by all 256 threads (it contains the block barrier).
-TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t lds_nodes, uint32_t lds_tris ) {
+TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
     const int tid = threadIdx.x;
     Tracer T;
     T.sc = sc;
@@ -43,7 +43,8 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.stack = words + tid;
     T.leaves = words + stack_depth * 256 + tid;
     T.stride = 256;
-    float4* stage = lds + ( stack_depth + TERRA_LEAF_CAP ) * 64;
+    T.leaf_cap = ( int ) leaf_cap;
+    float4* stage = lds + ( stack_depth + leaf_cap ) * 64;
     float4* ln = stage;
     float4* lt = ln + 4 * lds_nodes;
     float4* lp = lt + 3 * lds_tris;
@@ -73,7 +74,7 @@ template <int INTEGRATOR, bool COUNT, int MODE>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
-    const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.lds_nodes, p.lds_tris );
+    const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
 
     // block -> (own tile, 16x16 block in tile) -> pixel
     const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
@@ -156,25 +157,30 @@ static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank
     return tiles > rank ? ( tiles - rank + world - 1 ) / world : 0;
 }
 
-size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t lds_nodes, uint32_t lds_tris ) {
-    return ( size_t ) ( stack_depth + TERRA_LEAF_CAP ) * 1024 + ( size_t ) lds_nodes * 64 + ( size_t ) lds_tris * ( 48 + 64 );
+size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
+    return ( size_t ) ( stack_depth + leaf_cap ) * 1024 + ( size_t ) lds_nodes * 64 + ( size_t ) lds_tris * ( 48 + 64 );
 }
 
-// LDS plan: the whole scene if it fits the per-block budget, else the breadth-first node
-// prefix that fits, else nothing. The budget keeps 3 blocks (12 waves) per CU resident.
+// LDS plan. Small scenes (whole scene <= budget): stage everything; with the Cornell box that is
+// 27.5 KB per block, so the 5 blocks/CU the Simple kernel's registers allow stay resident.
+// Large scenes: nothing is staged -- their node fetches are bound by the L1 tag rate of divergent
+// 16-byte loads (each lane its own 64-B node), a staged prefix of ~100 nodes does not change that,
+// and a full-size leaf list (fewer drain phases) measured faster than the extra block of occupancy
+// a shorter list would buy (gpurun_out/ab4.log: 219 ms at 16 entries vs 228 ms at 10, 261 ms at 4).
+#ifndef TERRA_LDS_BUDGET
+#define TERRA_LDS_BUDGET ( 32 * 1024 )
+#endif
 void terra_plan_lds ( DevRenderParams& p ) {
-    const size_t budget = 48 * 1024;
+    const size_t budget = TERRA_LDS_BUDGET;
     uint32_t depth = p.scene.max_stack < 1 ? 1u : ( uint32_t ) p.scene.max_stack;
     p.stack_depth = depth;
-    size_t fixed = ( size_t ) ( depth + TERRA_LEAF_CAP ) * 1024;
+    p.leaf_cap = TERRA_LEAF_CAP_MAX;
     size_t whole = ( size_t ) p.scene.n_nodes * 64 + ( size_t ) p.scene.n_tris * 112;
-    if ( fixed + whole <= budget ) { p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris; return; }
-    p.lds_tris = 0;
-    size_t room = budget > fixed ? budget - fixed : 0;
-    uint32_t k = ( uint32_t ) ( room / 64 );
-    if ( k > p.scene.n_nodes ) k = p.scene.n_nodes;
-    if ( k >= 8 ) { p.lds_mode = 2; p.lds_nodes = k; }
-    else { p.lds_mode = 0; p.lds_nodes = 0; }
+    if ( ( size_t ) ( depth + TERRA_LEAF_CAP_MAX ) * 1024 + whole <= budget ) {
+        p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris;
+    } else {
+        p.lds_mode = 0; p.lds_nodes = 0; p.lds_tris = 0;
+    }
 }
 
 template <int I, int MODE>
@@ -195,7 +201,7 @@ hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) 
     uint32_t bpt = p.tile_size / 16;
     uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt;
     if ( blocks == 0 ) return hipSuccess;
-    size_t lds = terra_lds_bytes ( p.stack_depth, p.lds_nodes, p.lds_tris );
+    size_t lds = terra_lds_bytes ( p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
     switch ( p.integrator ) {
         case 0: return launch_one<0> ( p, blocks, lds, stream );
         case 1: return launch_one<1> ( p, blocks, lds, stream );

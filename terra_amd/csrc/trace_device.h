@@ -183,16 +183,14 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 // Tracer: where a thread finds the scene and its traversal scratch.
 //
 // LDS layout of a block (DESIGN.md "LDS"): [node stack: stack_depth x 256 ints]
-// [leaf list: TERRA_LEAF_CAP x 256 ints] [staged nodes: lds_nodes x 64 B]
+// [leaf list: leaf_cap x 256 ints] [staged nodes: lds_nodes x 64 B]
 // [staged triangles: lds_tris x 48 B] [staged vertex properties: lds_tris x 64 B].
 // Stack and leaf list are indexed [entry][thread] so the 64 lanes of a wave touch
 // 64 consecutive words (conflict free). Device node numbering is breadth first, so
 // the staged prefix [0, lds_nodes) is the top of the tree; triangles are staged only
 // when the whole soup fits.
 // -----------------------------------------------------------------------------
-#ifndef TERRA_LEAF_CAP
-#define TERRA_LEAF_CAP 16
-#endif
+#define TERRA_LEAF_CAP_MAX 16
 
 struct Tracer {
     DevScene      sc;
@@ -203,6 +201,7 @@ struct Tracer {
     int*          stack;       // this thread's column
     int*          leaves;
     int           stride;      // 256
+    int           leaf_cap;    // entries in the leaf list (>= 2)
 };
 
 // -----------------------------------------------------------------------------
@@ -289,7 +288,7 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     int top = 1, nleaf = 0;
     T.stack[0] = 0;
     for ( ;; ) {
-        while ( top > 0 && nleaf <= TERRA_LEAF_CAP - 2 ) {
+        while ( top > 0 && nleaf <= T.leaf_cap - 2 ) {
             uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
             float4 q0, q1, q2, q3;
             if ( MODE == 1 || ( MODE == 2 && ni < T.lds_nodes ) ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }

@@ -77,7 +77,7 @@ hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, c
 // unit kernels read the scene from global memory (MODE 0); LDS only holds stack + leaf list
 __device__ __forceinline__ Tracer unit_tracer ( const DevScene& sc, int* lds ) {
     Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.lds_nodes = 0; T.lds_tris = 0;
-    T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.stride = 256;
+    T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.stride = 256; T.leaf_cap = TERRA_LEAF_CAP_MAX;
     return T;
 }
 __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, c
     V3 pt = f ? r.o + r.d * b.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
     point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
 }
-static size_t stack_lds ( const DevScene& sc ) { return ( size_t ) ( ( sc.max_stack < 1 ? 1 : sc.max_stack ) + TERRA_LEAF_CAP ) * 256 * sizeof ( int ); }
+static size_t stack_lds ( const DevScene& sc ) { return ( size_t ) ( ( sc.max_stack < 1 ? 1 : sc.max_stack ) + TERRA_LEAF_CAP_MAX ) * 256 * sizeof ( int ); }
 hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
     hipLaunchKernelGGL ( k_bvh_traverse, UNIT_GRID ( n ), stack_lds ( sc ), 0, sc, n, o, d, found, prim, point );
     return hipGetLastError();

@@ -141,6 +141,157 @@ def cornell_phong(width=256, height=256, spp=4, bounces=8, integrator=api.kTerra
 
 
 # --------------------------------------------------------------------------
+# Sponza-class hall, ~100k triangles (configs 3, 5)
+# --------------------------------------------------------------------------
+# Generated with integer arithmetic, an integer hash and IEEE + - * / sqrt only (no
+# libm), so the float32 vertex data are bit-identical on every machine.
+
+def hash32(x):
+    x = np.asarray(x, dtype=np.uint32).copy()
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def _unit_circle(n):
+    """cos/sin of 2*pi*k/n for n a power of two, from half-angle square roots and one rotation recurrence"""
+    c, s, m = 0.0, 1.0, 4             # angle pi/2
+    while m < n:
+        c, s = np.sqrt((1.0 + c) / 2.0), np.sqrt((1.0 - c) / 2.0)
+        m *= 2
+    cs = np.zeros(n); sn = np.zeros(n)
+    cc, ss = 1.0, 0.0
+    for k in range(n):
+        cs[k], sn[k] = cc, ss
+        cc, ss = cc * c - ss * s, cc * s + ss * c
+    return cs, sn
+
+
+def _grid(P, N=None, flip=False):
+    """P: (ny, nx, 3) vertex grid -> triangles (2*(ny-1)*(nx-1), 3, 3) and per-vertex normals (given or face)"""
+    a, b, c, d = P[:-1, :-1], P[:-1, 1:], P[1:, 1:], P[1:, :-1]
+    t1 = np.stack([a, b, c], axis=-2); t2 = np.stack([a, c, d], axis=-2)
+    tris = np.concatenate([t1.reshape(-1, 3, 3), t2.reshape(-1, 3, 3)]).astype(np.float32)
+    if N is not None:
+        na, nb, nc, nd = N[:-1, :-1], N[:-1, 1:], N[1:, 1:], N[1:, :-1]
+        n1 = np.stack([na, nb, nc], axis=-2); n2 = np.stack([na, nc, nd], axis=-2)
+        nrm = np.concatenate([n1.reshape(-1, 3, 3), n2.reshape(-1, 3, 3)])
+    else:
+        f = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]).astype(np.float64)
+        f /= np.sqrt((f * f).sum(axis=1, keepdims=True))
+        nrm = np.repeat(f[:, None, :], 3, axis=1)
+    if flip:
+        nrm = -nrm
+    return tris, nrm.astype(np.float32)
+
+
+def _plane(origin, du, dv, nu, nv, normal):
+    u = np.arange(nu + 1, dtype=np.float64) / nu; v = np.arange(nv + 1, dtype=np.float64) / nv
+    P = np.asarray(origin, np.float64) + v[:, None, None] * np.asarray(dv, np.float64) + u[None, :, None] * np.asarray(du, np.float64)
+    N = np.broadcast_to(np.asarray(normal, np.float64), P.shape)
+    return _grid(P, N)
+
+
+def _albedo(seed, lo=0.35, hi=0.8):
+    h = hash32(np.arange(3, dtype=np.uint32) + np.uint32(seed * 977)).astype(np.float64) / 4294967296.0
+    return tuple(float(np.float32(lo + (hi - lo) * x)) for x in h)
+
+
+def sponza_hall(width=1920, height=1080, spp=256, bounces=8, integrator=api.kTerraIntegratorSimple, detail=1.0, **kw) -> SceneDesc:
+    """SURVEY.md section 8d 'Sponza-class-100k': hall x[-10,10] y[0,8] z[-5,5], heightfield floor
+    (hash noise, amplitude 0.05), tessellated walls/ceiling, 2x12 columns (32-gon prisms with flared
+    capitals), arches between columns, two gallery levels, 3 ceiling quad lights; 6 objects,
+    about 100,000 triangles at detail=1 (detail scales the tessellation for small test scenes)."""
+    def n(v):
+        return max(1, int(round(v * detail)))
+    parts = {}
+    # floor heightfield
+    nx, nz = n(160), n(80)
+    ix, iz = np.meshgrid(np.arange(nx + 1), np.arange(nz + 1))
+    hval = hash32((ix * 7919 + iz * 104729).astype(np.uint32)).astype(np.float64) / 4294967296.0
+    P = np.stack([-10.0 + 20.0 * ix / nx, 0.05 * hval, -5.0 + 10.0 * iz / nz], axis=-1)
+    hx = np.zeros_like(hval); hz = np.zeros_like(hval)
+    hx[:, 1:-1] = (P[:, 2:, 1] - P[:, :-2, 1]) / (P[:, 2:, 0] - P[:, :-2, 0])
+    hz[1:-1, :] = (P[2:, :, 1] - P[:-2, :, 1]) / (P[2:, :, 2] - P[:-2, :, 2])
+    N = np.stack([-hx, np.ones_like(hx), -hz], axis=-1); N /= np.sqrt((N * N).sum(axis=-1, keepdims=True))
+    parts["floor"] = [_grid(P, N)]
+    # shell: ceiling, two long walls, two end walls (normals into the hall)
+    parts["shell"] = [
+        _plane((-10, 8, -5), (20, 0, 0), (0, 0, 10), n(80), n(40), (0, -1, 0)),
+        _plane((-10, 0, 5), (20, 0, 0), (0, 8, 0), n(80), n(32), (0, 0, -1)),
+        _plane((-10, 0, -5), (20, 0, 0), (0, 8, 0), n(80), n(32), (0, 0, 1)),
+        _plane((-10, 0, -5), (0, 0, 10), (0, 8, 0), n(40), n(32), (1, 0, 0)),
+        _plane((10, 0, -5), (0, 0, 10), (0, 8, 0), n(40), n(32), (-1, 0, 0)),
+    ]
+    # columns: 2 rows x 12, radius 0.3, height 5, flared capital to radius 0.5 over the top 0.5
+    seg = 32 if detail >= 0.5 else 8
+    cs, sn = _unit_circle(seg)
+    cs = np.append(cs, cs[0]); sn = np.append(sn, sn[0])
+    rings = n(24)
+    ys = np.concatenate([np.arange(rings + 1) * (4.5 / rings), 4.5 + np.arange(1, 5) * 0.125])
+    rad = np.concatenate([np.full(rings + 1, 0.3), 0.3 + np.arange(1, 5) * 0.05])
+    slope = np.concatenate([np.zeros(rings + 1), np.full(4, 0.4)])          # radial growth per unit height in the capital
+    cols = []
+    for row, zc in enumerate((-2.5, 2.5)):
+        for k in range(12):
+            xc = -8.25 + 1.5 * k
+            P = np.stack([xc + rad[:, None] * cs[None, :], np.broadcast_to(ys[:, None], (len(ys), seg + 1)), zc + rad[:, None] * sn[None, :]], axis=-1)
+            N = np.stack([np.broadcast_to(cs[None, :], (len(ys), seg + 1)), np.broadcast_to(-slope[:, None], (len(ys), seg + 1)), np.broadcast_to(sn[None, :], (len(ys), seg + 1))], axis=-1).copy()
+            N /= np.sqrt((N * N).sum(axis=-1, keepdims=True))
+            cols.append(_grid(P, N))
+    parts["columns"] = cols
+    # arches: half rings spanning neighbouring columns (in x), square-ish cross-section as a 6-gon tube
+    a_seg = n(16)
+    th_c, th_s = _unit_circle(4 * max(4, a_seg))       # quarter resolution; take the upper half circle
+    half = len(th_c) // 2
+    tc, ts = th_c[: half + 1], th_s[: half + 1]
+    step = max(1, half // a_seg)
+    tc, ts = tc[::step], ts[::step]
+    c8, s8 = _unit_circle(8)
+    pick6 = [0, 1, 2, 4, 5, 6, 0]                       # a closed 6-gon cross-section from the octagon's vertices
+    hc, hs = c8[pick6], s8[pick6]
+    arches = []
+    for zc in (-2.5, 2.5):
+        for k in range(11):
+            xm = -8.25 + 1.5 * k + 0.75
+            R, r = 0.75, 0.08
+            cx = xm + (R + r * hc[None, :]) * tc[:, None]
+            cy = 5.0 + (R + r * hc[None, :]) * ts[:, None]
+            cz = zc + r * hs[None, :] * np.ones_like(tc)[:, None]
+            P = np.stack([cx, cy, cz], axis=-1)
+            N = np.stack([hc[None, :] * tc[:, None], hc[None, :] * ts[:, None], hs[None, :] * np.ones_like(tc)[:, None]], axis=-1)
+            N /= np.sqrt((N * N).sum(axis=-1, keepdims=True))
+            arches.append(_grid(P, N))
+    parts["arches"] = arches
+    # galleries: two levels on both sides: top and bottom faces + inner edge
+    gal = []
+    for y0 in (3.0, 5.9):
+        for zs, z0, z1 in ((-1, -5.0, -3.2), (1, 3.2, 5.0)):
+            gal.append(_plane((-10, y0 + 0.2, z0), (20, 0, 0), (0, 0, z1 - z0), n(40), n(4), (0, 1, 0)))
+            gal.append(_plane((-10, y0, z0), (20, 0, 0), (0, 0, z1 - z0), n(40), n(4), (0, -1, 0)))
+            ze = z1 if zs < 0 else z0
+            gal.append(_plane((-10, y0, ze), (20, 0, 0), (0, 0.2, 0), n(40), 1, (0, 0, -float(zs))))
+    parts["galleries"] = gal
+    # lights: three ceiling quads
+    parts["lights"] = [_plane((xc - 0.6, 7.98, -0.6), (1.2, 0, 0), (0, 0, 1.2), 1, 1, (0, -1, 0)) for xc in (-6.0, 0.0, 6.0)]
+
+    objs = []
+    for i, (name, plist) in enumerate(parts.items()):
+        tris = np.concatenate([p[0] for p in plist]).astype(np.float32)
+        nrm = np.concatenate([p[1] for p in plist]).astype(np.float32)
+        uv = np.zeros((len(tris), 3, 2), np.float32)
+        mat = Material(albedo=(0.78, 0.78, 0.78), emissive=(12.0, 11.0, 9.0)) if name == "lights" else Material(albedo=_albedo(i + 1))
+        objs.append(ObjectDesc(np.ascontiguousarray(tris), np.ascontiguousarray(nrm), uv, mat, name))
+    d = SceneDesc(objects=objs, width=width, height=height, spp=spp, bounces=bounces, integrator=integrator,
+                  camera_position=(-9.2, 2.2, 0.35), camera_direction=(1.0, 0.06, -0.04), camera_up=(0.0, 1.0, 0.0), camera_fov=60.0,
+                  name="sponza_hall" if detail == 1.0 else f"sponza_hall_d{detail}")
+    for k2, v in kw.items():
+        setattr(d, k2, v)
+    return d
+
+
+# --------------------------------------------------------------------------
 # feeding a SceneDesc through the C API
 # --------------------------------------------------------------------------
 

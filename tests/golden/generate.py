@@ -114,6 +114,22 @@ def main():
     small["tile_pixels"] = o4["pixels"]; small["tile_samples"] = o4["samples"]
     manifest["files"]["render_small"] = save("render_small", **small)
 
+    # config 3 geometry: the ~100k-triangle hall (deep reference-tree traversal), small frames
+    hall = {}
+    for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
+        o5 = ref.render_pixels(scenes.sponza_hall(w, h, spp, integrator=integ))
+        hall[f"i{integ}_pixels"] = o5["pixels"]; hall[f"i{integ}_calls"] = o5["rand_calls"].astype(np.uint16)
+    dh = scenes.sponza_hall(64, 36, 1)
+    sc = scenes.build_scene(L, dh)
+    nodes = ref.bvh_nodes(sc)
+    hall["bvh_sha256"] = np.frombuffer(bytes.fromhex(H.digest(nodes)), dtype=np.uint8)
+    hall["bvh_nodes"] = np.int64(len(nodes))
+    o, dd = H.scene_rays(71, 512, box=((-9.5, 0.3, -4.5), (9.5, 7.5, 4.5)))
+    found, prim, point = ref.bvh_traverse(sc, o, dd)
+    hall["trav_found"] = found; hall["trav_prim"] = prim; hall["trav_point"] = point
+    L.scene_destroy(sc)
+    manifest["files"]["render_hall"] = save("render_hall", **hall)
+
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1))
     total = sum(p.stat().st_size for p in HERE.glob("*.npz"))
     print(f"wrote {len(manifest['files'])} fixtures, {total / 1e6:.2f} MB")

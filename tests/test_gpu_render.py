@@ -263,3 +263,39 @@ def test_full_hd_properties(H, L, orc_lib, devmath_mode):
     want = H.Unit("orc").render_pixels(d, rect=(x0, y0, w, h), want_calls=False)
     assert H.same_bits(full["pixels"][y0:y0 + h, x0:x0 + w], want["pixels"][y0:y0 + h, x0:x0 + w])
     L.scene_destroy(scene)
+
+
+# ---------------------------------------------------------------------------
+# config 3 geometry: ~100k-triangle hall (LDS holds only a node prefix; triangles from global memory)
+# ---------------------------------------------------------------------------
+
+def test_hall_100k_goldens(H, L):
+    g = G(H, "render_hall")
+    d = scenes.sponza_hall(64, 36, 1)
+    scene = scenes.build_scene(L, d)
+    assert runtime.last_error() == "", runtime.last_error()
+    U = H.Unit("amd")
+    nodes = U.bvh_nodes(scene)
+    assert len(nodes) == int(g["bvh_nodes"]) and H.digest(nodes) == bytes(g["bvh_sha256"]).hex()
+    o, dd = H.scene_rays(71, 512, box=((-9.5, 0.3, -4.5), (9.5, 7.5, 4.5)))
+    found, prim, point = U.bvh_traverse(scene, o, dd)
+    assert np.array_equal(found, g["trav_found"]) and np.array_equal(prim, g["trav_prim"]) and H.same_bits(point, g["trav_point"])
+    L.scene_destroy(scene)
+    for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
+        out = render_dev(L, scenes.sponza_hall(w, h, spp, integrator=integ), calls=True)
+        assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]), integ
+        assert np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32)), integ
+        host = render_host(L, scenes.sponza_hall(w, h, spp, integrator=integ))
+        assert H.same_bits(host["pixels"], g[f"i{integ}_pixels"]), integ
+
+
+def test_hall_full_hd_crop_vs_oracle_and_tiles(H, L, orc_lib, devmath_mode):
+    """BASELINE.json configs[2] geometry at 1080p (reduced spp): a crop against the oracle, tile invariance"""
+    d = scenes.sponza_hall(1920, 1080, 2, integrator=2)
+    full = render_dev(L, d)
+    x0, y0, w, h = 1000, 600, 40, 24
+    want = H.Unit("orc").render_pixels(d, rect=(x0, y0, w, h), want_calls=False)
+    assert H.same_bits(full["pixels"][y0:y0 + h, x0:x0 + w], want["pixels"][y0:y0 + h, x0:x0 + w])
+    part = render_dev(L, d, rect=(960, 512, 192, 128))
+    assert H.same_bits(part["pixels"][512:640, 960:1152], full["pixels"][512:640, 960:1152])
+    assert full["stats"]["samples"] == 1920 * 1080 * 2
