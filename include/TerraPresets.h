@@ -44,6 +44,30 @@ typedef struct {
     bool        sample_diffuse;
 } TerraMaterialPhong;
 
+/* ---- presets the reference does not have in runnable form ------------------------------
+ * BASELINE.json config 4 asks for a GGX metal and a dielectric glass. The reference only
+ * contains dead code for them (src/TerraPresets.c:298-465, inside #if 0, written against a
+ * removed API), so there is NO reference behaviour to match: these two presets are DEFINED
+ * here, in the live sample/pdf/eval form, from that code's building blocks (GGX D :316-320,
+ * Smith G1 :307-314, half-vector sampling :333-343, Snell/TIR/Schlick :399-449). Parity for
+ * them is device vs this repo's oracle only ("parity unpinned" vs the reference).
+ *
+ * GGX conductor:  attributes[0] = F0 (specular colour), attributes[1].x = roughness alpha.
+ * Glass:          attributes[0] = tint, material.ior = index of refraction; attributes[2]
+ *                 and attributes[3].x are scratch written by sample() (the chosen direction and
+ *                 its probability), like Phong's slot 3. */
+#define TERRA_GGX_F0        0
+#define TERRA_GGX_ROUGHNESS 1
+#define TERRA_GGX_END       2
+void terra_bsdf_ggx_init ( TerraBSDF* bsdf );
+
+#define TERRA_GLASS_TINT        0
+#define TERRA_GLASS_UNUSED      1
+#define TERRA_GLASS_SAMPLE_DIR  2
+#define TERRA_GLASS_SAMPLE_PROB 3
+#define TERRA_GLASS_END         4
+void terra_bsdf_glass_init ( TerraBSDF* bsdf );
+
 #define TERRA_DISNEY_BASE_COLOR 0
 #define TERRA_DISNEY_SHEEN      1
 

@@ -144,8 +144,8 @@ int terra_amd_unit_bvh_traverse ( HTerraScene scene, int n, const float* origins
 int terra_amd_unit_raycast ( HTerraScene scene, int n, const float* origins3, const float* dirs3, int* obj, int* tri, float* point3, float* surface47 );
 /* terra_trace (src/Terra.c:1039-1097) for n primary rays with explicit stream-B state: radiance3, rand_calls */
 int terra_amd_unit_trace ( HTerraScene scene, int n, const float* origins3, const float* dirs3, const uint64_t* stateB, const uint64_t* incB, float* radiance3, uint32_t* rand_calls );
-/* BSDF presets (src/TerraPresets.c:34-146). kind: 0 diffuse, 1 phong. surfaces47 in/out (Phong
-   writes the sample-pick slot). Per item: e[3], wo[3] -> wi[3], pdf, f[3] (pdf/eval at the sampled wi) */
+/* BSDF presets (src/TerraPresets.c:34-146). kind: 0 diffuse, 1 phong, 2 GGX, 3 glass (the last two are
+   this library's own definitions, TerraPresets.h). surfaces47 in/out (Phong and glass write scratch slots). Per item: e[3], wo[3] -> wi[3], pdf, f[3] (pdf/eval at the sampled wi) */
 int terra_amd_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 );
 /* camera (src/Terra.c:1770-1799): dirs3 in world space for pixel (x,y), jitter, r1, r2 */
 int terra_amd_unit_camera ( const TerraCamera* camera, size_t fb_width, size_t fb_height, int n, const uint32_t* xy2, float jitter, const float* r2, float* dirs3 );

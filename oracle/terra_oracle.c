@@ -705,6 +705,106 @@ static TerraFloat3 phong_eval ( const TerraShadingSurface* sf, const TerraFloat3
 void orc_bsdf_phong_init ( TerraBSDF* b ) { b->sample = phong_sample; b->pdf = phong_pdf; b->eval = phong_eval; }
 
 /* ------------------------------------------------------------------------- */
+/* A14: GGX conductor and dielectric glass -- NO LIVE REFERENCE ("parity unpinned").     */
+/* Defined by this repo (include/TerraPresets.h) from the building blocks of the         */
+/* reference's dead code (src/TerraPresets.c:303-320 D and G1, :333-343 half-vector       */
+/* sampling, :399-449 Snell / TIR / Schlick). Only + - * / sqrt and the pinned sinf/cosf. */
+/* ------------------------------------------------------------------------- */
+static float ggx_D ( float NoH, float alpha2 ) {                 /* :316-320 */
+    if ( NoH <= 0.f ) return 0.f;
+    float NoH2 = NoH * NoH;
+    float den = NoH2 * alpha2 + ( 1 - NoH2 );
+    return alpha2 / ( terra_PI * den * den );
+}
+static float ggx_G1 ( v3 v, v3 n, v3 h, float alpha2 ) {         /* :307-314 */
+    /* Smith G1 for GGX (Walter et al. 2007, eq. 34). The dead code takes the tangent of the angle to
+       the HALF vector (:311-312), which over-weights grazing lobes (mean path weight > 1); the angle to
+       the NORMAL is used here. */
+    float VoH = v3_dot ( v, h ), VoN = v3_dot ( v, n );
+    if ( VoH / VoN <= 0.f ) return 0.f;
+    float VoN2 = VoN * VoN;
+    float tan2 = ( 1.f - VoN2 ) / VoN2;
+    return 2.f / ( sqrtf ( 1 + alpha2 * tan2 ) + 1 );
+}
+static TerraFloat3 ggx_sample ( const TerraShadingSurface* sf, float e1, float e2, float e3, const TerraFloat3* wo ) {
+    ( void ) e3;
+    float alpha = sf->attributes[TERRA_GGX_ROUGHNESS].x;
+    float t2 = alpha * alpha * e1 / ( 1.f - e1 );                /* tan^2(theta_h), :337 without the atan */
+    float cos_t = 1.f / sqrtf ( 1.f + t2 );
+    float sin_t = sqrtf ( sel_max ( 0.f, 1.f - cos_t * cos_t ) );
+    float phi = 2 * terra_PI * e2;
+    v3 h = v3_set ( sin_t * orc_math_cosf ( phi ), cos_t, sin_t * orc_math_sinf ( phi ) );
+    h = v3_norm ( m3_apply ( &sf->transform, h ) );
+    float HoV = sel_max ( 0.f, v3_dot ( h, *wo ) );
+    return v3_sub ( v3_scale ( h, 2 * HoV ), *wo );              /* :345-346 */
+}
+static float ggx_pdf ( const TerraShadingSurface* sf, const TerraFloat3* wi, const TerraFloat3* wo ) {
+    float alpha = sf->attributes[TERRA_GGX_ROUGHNESS].x;
+    v3 h = v3_norm ( v3_add ( *wi, *wo ) );
+    float NoH = v3_dot ( sf->normal, h ), HoV = v3_dot ( h, *wo );
+    if ( HoV <= 0.f ) return 0.f;
+    return ggx_D ( NoH, alpha * alpha ) * NoH / ( 4.f * HoV );
+}
+static TerraFloat3 ggx_eval ( const TerraShadingSurface* sf, const TerraFloat3* wi, const TerraFloat3* wo ) {
+    float alpha = sf->attributes[TERRA_GGX_ROUGHNESS].x, alpha2 = alpha * alpha;
+    float NoL = v3_dot ( sf->normal, *wi ), NoV = v3_dot ( sf->normal, *wo );
+    if ( NoL <= 0.f || NoV <= 0.f ) return v3_set ( 0, 0, 0 );
+    v3 h = v3_norm ( v3_add ( *wi, *wo ) );
+    float NoH = v3_dot ( sf->normal, h ), HoV = sel_max ( 0.f, v3_dot ( h, *wo ) );
+    float m = 1.f - HoV, m2 = m * m, w5 = m2 * m2 * m;          /* Schlick weight */
+    v3 F0 = sf->attributes[TERRA_GGX_F0];
+    v3 F = v3_set ( F0.x + ( 1.f - F0.x ) * w5, F0.y + ( 1.f - F0.y ) * w5, F0.z + ( 1.f - F0.z ) * w5 );
+    float G = ggx_G1 ( *wo, sf->normal, h, alpha2 ) * ggx_G1 ( *wi, sf->normal, h, alpha2 );
+    float k = G * ggx_D ( NoH, alpha2 ) / ( 4.f * NoL * NoV );
+    return v3_scale ( F, k );
+}
+void orc_bsdf_ggx_init ( TerraBSDF* b ) { b->sample = ggx_sample; b->pdf = ggx_pdf; b->eval = ggx_eval; }
+
+static TerraFloat3 glass_sample ( const TerraShadingSurface* sf, float e1, float e2, float e3, const TerraFloat3* wo ) {
+    ( void ) e1; ( void ) e2;
+    TerraFloat3* sdir = ( TerraFloat3* ) &sf->attributes[TERRA_GLASS_SAMPLE_DIR];
+    TerraFloat3* sprob = ( TerraFloat3* ) &sf->attributes[TERRA_GLASS_SAMPLE_PROB];
+    v3 normal = sf->normal, incident = v3_neg ( *wo );
+    float n1, n2, cos_i = v3_dot ( normal, incident );
+    if ( cos_i > 0.f ) { n1 = sf->ior; n2 = terra_ior_air; normal = v3_neg ( normal ); }      /* leaving the medium, :409-413 */
+    else { n1 = terra_ior_air; n2 = sf->ior; cos_i = -cos_i; }
+    v3 refl = v3_sub ( incident, v3_scale ( normal, 2 * v3_dot ( normal, incident ) ) );
+    float nni = n1 / n2;
+    float cos_t2 = 1.f - nni * nni * ( 1.f - cos_i * cos_i );
+    v3 dir; float prob;
+    if ( cos_t2 < 0.f ) { dir = refl; prob = 1.f; }                                      /* total internal reflection, :424-427 */
+    else {
+        float cos_t = sqrtf ( cos_t2 );
+        float t = 1.f - ( n1 <= n2 ? cos_i : cos_t );
+        float R0 = ( n1 - n2 ) / ( n1 + n2 ); R0 *= R0;
+        float R = R0 + ( 1 - R0 ) * ( t * t * t * t * t );
+        if ( e3 < R ) { dir = refl; prob = R; }
+        else {
+            v3 tv = v3_scale ( normal, nni * cos_i - cos_t ), tn = v3_scale ( incident, nni );
+            dir = v3_norm ( v3_add ( tv, tn ) ); prob = 1 - R;
+        }
+    }
+    *sdir = dir; sprob->x = prob;
+    return dir;
+}
+static bool glass_is_sampled ( const TerraShadingSurface* sf, const TerraFloat3* wi ) {
+    const TerraFloat3* d = &sf->attributes[TERRA_GLASS_SAMPLE_DIR];
+    return sf->attributes[TERRA_GLASS_SAMPLE_PROB].x > 0.f && wi->x == d->x && wi->y == d->y && wi->z == d->z;
+}
+static float glass_pdf ( const TerraShadingSurface* sf, const TerraFloat3* wi, const TerraFloat3* wo ) {
+    ( void ) wo;
+    return glass_is_sampled ( sf, wi ) ? sf->attributes[TERRA_GLASS_SAMPLE_PROB].x : 0.f;     /* a delta lobe: zero for any other direction */
+}
+static TerraFloat3 glass_eval ( const TerraShadingSurface* sf, const TerraFloat3* wi, const TerraFloat3* wo ) {
+    ( void ) wo;
+    if ( !glass_is_sampled ( sf, wi ) ) return v3_set ( 0, 0, 0 );
+    /* terra_trace multiplies eval/pdf by the SIGNED dot(n, wi): divide it out so the path weight is the tint */
+    float k = sf->attributes[TERRA_GLASS_SAMPLE_PROB].x / v3_dot ( sf->normal, *wi );
+    return v3_scale ( sf->attributes[TERRA_GLASS_TINT], k );
+}
+void orc_bsdf_glass_init ( TerraBSDF* b ) { b->sample = glass_sample; b->pdf = glass_pdf; b->eval = glass_eval; }
+
+/* ------------------------------------------------------------------------- */
 /* lights (reference src/Terra.c:1592-1621, :1662-1697, :1833-1838)            */
 /* ------------------------------------------------------------------------- */
 static float triangle_area ( const TerraTriangle* t ) {

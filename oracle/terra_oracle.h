@@ -55,6 +55,8 @@ void               orc_free ( void* ptr );
 void               orc_log ( const char* str, ... );
 void               orc_bsdf_diffuse_init ( TerraBSDF* bsdf );
 void               orc_bsdf_phong_init ( TerraBSDF* bsdf );
+void               orc_bsdf_ggx_init ( TerraBSDF* bsdf );      /* no live reference: defined by this repo, see TerraPresets.h */
+void               orc_bsdf_glass_init ( TerraBSDF* bsdf );
 
 /* ---- checker controls -------------------------------------------------------- */
 enum { ORC_MATH_LIBM = 0, ORC_MATH_DEVMATH = 1 };

@@ -32,6 +32,8 @@ kTerraIntegratorSimple, kTerraIntegratorDirect, kTerraIntegratorDirectMis, kTerr
 # preset attribute slots, reference include/TerraPresets.h:11-26
 TERRA_DIFFUSE_ALBEDO, TERRA_DIFFUSE_END = 0, 1
 TERRA_PHONG_SPECULAR_COLOR, TERRA_PHONG_ALBEDO, TERRA_PHONG_SPECULAR_INTENSITY, TERRA_PHONG_SAMPLE_PICK, TERRA_PHONG_END = 0, 1, 2, 3, 4
+TERRA_GGX_F0, TERRA_GGX_ROUGHNESS, TERRA_GGX_END = 0, 1, 2
+TERRA_GLASS_TINT, TERRA_GLASS_UNUSED, TERRA_GLASS_SAMPLE_DIR, TERRA_GLASS_SAMPLE_PROB, TERRA_GLASS_END = 0, 1, 2, 3, 4
 
 
 class TerraFloat2(Structure):
@@ -162,7 +164,11 @@ API_SIGNATURES = {
     "log": (None, None),  # variadic
     "bsdf_diffuse_init": (None, [POINTER(TerraBSDF)]),
     "bsdf_phong_init": (None, [POINTER(TerraBSDF)]),
+    "bsdf_ggx_init": (None, [POINTER(TerraBSDF)]),
+    "bsdf_glass_init": (None, [POINTER(TerraBSDF)]),
 }
+# not part of the reference API: absent from the compiled reference
+OPTIONAL_SYMBOLS = {"bsdf_ggx_init", "bsdf_glass_init"}
 
 
 class TerraLib:
@@ -178,7 +184,8 @@ class TerraLib:
             try:
                 fn = getattr(self.dll, sym)
             except AttributeError:
-                self.missing.append(sym)
+                if name not in OPTIONAL_SYMBOLS:
+                    self.missing.append(sym)
                 continue
             fn.restype = res
             if args is not None:

@@ -51,7 +51,7 @@ struct DevProps {
 };
 static_assert ( sizeof ( DevProps ) == 64, "DevProps must be 64 bytes" );
 
-enum DevBsdfKind { kDevBsdfDiffuse = 0, kDevBsdfPhong = 1 };
+enum DevBsdfKind { kDevBsdfDiffuse = 0, kDevBsdfPhong = 1, kDevBsdfGGX = 2, kDevBsdfGlass = 3 };
 
 struct DevMaterial {
     int32_t  bsdf;                 // DevBsdfKind

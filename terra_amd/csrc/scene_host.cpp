@@ -85,6 +85,14 @@ TerraFloat3 terra_bsdf_diffuse_eval ( const TerraShadingSurface*, const TerraFlo
 TerraFloat3 terra_bsdf_phong_sample ( const TerraShadingSurface*, float, float, float, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_phong_sample" ); }
 float       terra_bsdf_phong_pdf ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { host_call_refused ( "terra_bsdf_phong_pdf" ); return 0.f; }
 TerraFloat3 terra_bsdf_phong_eval ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_phong_eval" ); }
+TerraFloat3 terra_bsdf_ggx_sample ( const TerraShadingSurface*, float, float, float, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_ggx_sample" ); }
+float       terra_bsdf_ggx_pdf ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { host_call_refused ( "terra_bsdf_ggx_pdf" ); return 0.f; }
+TerraFloat3 terra_bsdf_ggx_eval ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_ggx_eval" ); }
+TerraFloat3 terra_bsdf_glass_sample ( const TerraShadingSurface*, float, float, float, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_glass_sample" ); }
+float       terra_bsdf_glass_pdf ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { host_call_refused ( "terra_bsdf_glass_pdf" ); return 0.f; }
+TerraFloat3 terra_bsdf_glass_eval ( const TerraShadingSurface*, const TerraFloat3*, const TerraFloat3* ) { return host_call_refused ( "terra_bsdf_glass_eval" ); }
+void terra_bsdf_ggx_init ( TerraBSDF* b ) { b->sample = terra_bsdf_ggx_sample; b->pdf = terra_bsdf_ggx_pdf; b->eval = terra_bsdf_ggx_eval; }
+void terra_bsdf_glass_init ( TerraBSDF* b ) { b->sample = terra_bsdf_glass_sample; b->pdf = terra_bsdf_glass_pdf; b->eval = terra_bsdf_glass_eval; }
 void terra_bsdf_diffuse_init ( TerraBSDF* b ) { b->sample = terra_bsdf_diffuse_sample; b->pdf = terra_bsdf_diffuse_pdf; b->eval = terra_bsdf_diffuse_eval; }
 void terra_bsdf_phong_init ( TerraBSDF* b ) { b->sample = terra_bsdf_phong_sample; b->pdf = terra_bsdf_phong_pdf; b->eval = terra_bsdf_phong_eval; }
 }
@@ -399,6 +407,8 @@ static float triangle_area ( const TerraTriangle& t ) {
 }
 
 static bool is_diffuse ( const TerraBSDF& b ) { return b.sample == terra_bsdf_diffuse_sample && b.pdf == terra_bsdf_diffuse_pdf && b.eval == terra_bsdf_diffuse_eval; }
+static bool is_ggx ( const TerraBSDF& b ) { return b.sample == terra_bsdf_ggx_sample && b.pdf == terra_bsdf_ggx_pdf && b.eval == terra_bsdf_ggx_eval; }
+static bool is_glass ( const TerraBSDF& b ) { return b.sample == terra_bsdf_glass_sample && b.pdf == terra_bsdf_glass_pdf && b.eval == terra_bsdf_glass_eval; }
 static bool is_phong ( const TerraBSDF& b ) { return b.sample == terra_bsdf_phong_sample && b.pdf == terra_bsdf_phong_pdf && b.eval == terra_bsdf_phong_eval; }
 
 // validates that every material can run on the device and uploads the flattened scene
@@ -416,6 +426,8 @@ static int upload_scene ( Scene* s ) {
         DevMaterial& d = mats[j];
         if ( is_diffuse ( m.bsdf ) ) d.bsdf = kDevBsdfDiffuse;
         else if ( is_phong ( m.bsdf ) ) d.bsdf = kDevBsdfPhong;
+        else if ( is_ggx ( m.bsdf ) ) d.bsdf = kDevBsdfGGX;
+        else if ( is_glass ( m.bsdf ) ) d.bsdf = kDevBsdfGlass;
         else return fail ( kTerraAmdErrUnsupported, "object %zu: BSDF function pointers are not a terra_bsdf_*_init preset of this library; host callbacks cannot run on the device", j );
         if ( m.attributes_count > TERRA_MATERIAL_MAX_ATTRIBUTES ) return fail ( kTerraAmdErrBadArgument, "object %zu: attributes_count %zu > %d", j, m.attributes_count, TERRA_MATERIAL_MAX_ATTRIBUTES );
         if ( m.emissive.state != nullptr ) return fail ( kTerraAmdErrUnsupported, "object %zu: textured emissive is not supported on the device yet", j );
@@ -843,7 +855,7 @@ extern "C" int terra_amd_unit_trace ( HTerraScene hs, int n, const float* o, con
 }
 extern "C" int terra_amd_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 ) {
     if ( need_device() ) return kTerraAmdErrNoDevice;
-    if ( kind != kDevBsdfDiffuse && kind != kDevBsdfPhong ) return fail ( kTerraAmdErrBadArgument, "unknown bsdf kind %d", kind );
+    if ( kind < kDevBsdfDiffuse || kind > kDevBsdfGlass ) return fail ( kTerraAmdErrBadArgument, "unknown bsdf kind %d", kind );
     Unit u; auto sf = u.inout ( surfaces47, 47 * ( size_t ) n ); auto e = u.in ( e3, 3 * ( size_t ) n ); auto wo = u.in ( wo3, 3 * ( size_t ) n );
     auto wi = u.out ( wi3, 3 * ( size_t ) n ); auto pd = u.out ( pdf, n ); auto f = u.out ( f3, 3 * ( size_t ) n );
     return u.finish ( u.ok ? terra_unit_bsdf ( kind, n, sf, e, wo, wi, pd, f ) : hipSuccess );

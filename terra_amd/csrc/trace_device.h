@@ -346,7 +346,8 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 struct Surface {
     V3    normal;
     V3    emissive;
-    V3    attr[4];      // the presets use at most 4 slots (Phong); slot 3.x is Phong's sample-pick scratch
+    V3    attr[4];      // the presets use at most 4 slots; Phong slot 3.x and glass slots 2, 3.x are scratch written by sample()
+    float ior;
     int   bsdf;
 };
 
@@ -381,6 +382,7 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
     #pragma unroll
     for ( int i = 0; i < 4; ++i ) sf.attr[i] = v3p ( m.attributes[i] );
     sf.bsdf = m.bsdf;
+    sf.ior = m.ior;
     nattr_out = m.attributes_count;
 }
 
@@ -465,16 +467,104 @@ TD V3 phong_eval ( const Surface& sf, V3 wi, V3 wo ) {
     return diffuse_term + specular_term;
 }
 
+// ---- GGX conductor and dielectric glass: defined by this repo (include/TerraPresets.h), no live
+// reference; building blocks from the reference's dead code (src/TerraPresets.c:303-320, 333-343, 399-449)
+TD float ggx_D ( float NoH, float alpha2 ) {
+    if ( NoH <= 0.f ) return 0.f;
+    float NoH2 = NoH * NoH;
+    float den = NoH2 * alpha2 + ( 1 - NoH2 );
+    return alpha2 / ( TERRA_PI_F * den * den );
+}
+TD float ggx_G1 ( V3 v, V3 n, V3 h, float alpha2 ) {
+    float VoH = dot ( v, h ), VoN = dot ( v, n );
+    if ( VoH / VoN <= 0.f ) return 0.f;
+    float VoN2 = VoN * VoN;
+    float tan2 = ( 1.f - VoN2 ) / VoN2;        // Smith G1 w.r.t. the normal (Walter 2007 eq. 34), see oracle note
+    return 2.f / ( sqrtf ( 1 + alpha2 * tan2 ) + 1 );
+}
+TD V3 ggx_sample ( const Surface& sf, float e1, float e2, V3 wo ) {
+    float alpha = sf.attr[1].x;
+    float t2 = alpha * alpha * e1 / ( 1.f - e1 );
+    float cos_t = 1.f / sqrtf ( 1.f + t2 );
+    float sin_t = sqrtf ( sel_max ( 0.f, 1.f - cos_t * cos_t ) );
+    float phi = 2 * TERRA_PI_F * e2;
+    float sn, cs;
+    tdm_sincosf_pair ( phi, sn, cs );
+    V3 h = v3 ( sin_t * cs, cos_t, sin_t * sn );
+    h = normalize ( basis_apply ( make_basis ( sf.normal ), h ) );
+    float HoV = sel_max ( 0.f, dot ( h, wo ) );
+    return h * ( 2 * HoV ) - wo;
+}
+TD float ggx_pdf ( const Surface& sf, V3 wi, V3 wo ) {
+    float alpha = sf.attr[1].x;
+    V3 h = normalize ( wi + wo );
+    float NoH = dot ( sf.normal, h ), HoV = dot ( h, wo );
+    if ( HoV <= 0.f ) return 0.f;
+    return ggx_D ( NoH, alpha * alpha ) * NoH / ( 4.f * HoV );
+}
+TD V3 ggx_eval ( const Surface& sf, V3 wi, V3 wo ) {
+    float alpha = sf.attr[1].x, alpha2 = alpha * alpha;
+    float NoL = dot ( sf.normal, wi ), NoV = dot ( sf.normal, wo );
+    if ( NoL <= 0.f || NoV <= 0.f ) return v3 ( 0, 0, 0 );
+    V3 h = normalize ( wi + wo );
+    float NoH = dot ( sf.normal, h ), HoV = sel_max ( 0.f, dot ( h, wo ) );
+    float m = 1.f - HoV, m2 = m * m, w5 = m2 * m2 * m;
+    V3 F0 = sf.attr[0];
+    V3 F = v3 ( F0.x + ( 1.f - F0.x ) * w5, F0.y + ( 1.f - F0.y ) * w5, F0.z + ( 1.f - F0.z ) * w5 );
+    float G = ggx_G1 ( wo, sf.normal, h, alpha2 ) * ggx_G1 ( wi, sf.normal, h, alpha2 );
+    float k = G * ggx_D ( NoH, alpha2 ) / ( 4.f * NoL * NoV );
+    return F * k;
+}
+TD V3 glass_sample ( Surface& sf, float e3, V3 wo ) {
+    V3 normal = sf.normal, incident = neg ( wo );
+    float n1, n2, cos_i = dot ( normal, incident );
+    if ( cos_i > 0.f ) { n1 = sf.ior; n2 = 1.f; normal = neg ( normal ); }
+    else { n1 = 1.f; n2 = sf.ior; cos_i = -cos_i; }
+    V3 refl = incident - normal * ( 2 * dot ( normal, incident ) );
+    float nni = n1 / n2;
+    float cos_t2 = 1.f - nni * nni * ( 1.f - cos_i * cos_i );
+    V3 dir; float prob;
+    if ( cos_t2 < 0.f ) { dir = refl; prob = 1.f; }
+    else {
+        float cos_t = sqrtf ( cos_t2 );
+        float t = 1.f - ( n1 <= n2 ? cos_i : cos_t );
+        float R0 = ( n1 - n2 ) / ( n1 + n2 ); R0 *= R0;
+        float R = R0 + ( 1 - R0 ) * ( t * t * t * t * t );
+        if ( e3 < R ) { dir = refl; prob = R; }
+        else {
+            V3 tv = normal * ( nni * cos_i - cos_t ), tn = incident * nni;
+            dir = normalize ( tv + tn ); prob = 1 - R;
+        }
+    }
+    sf.attr[2] = dir; sf.attr[3].x = prob;
+    return dir;
+}
+TD bool glass_is_sampled ( const Surface& sf, V3 wi ) {
+    return sf.attr[3].x > 0.f && wi.x == sf.attr[2].x && wi.y == sf.attr[2].y && wi.z == sf.attr[2].z;
+}
+TD float glass_pdf ( const Surface& sf, V3 wi ) { return glass_is_sampled ( sf, wi ) ? sf.attr[3].x : 0.f; }
+TD V3 glass_eval ( const Surface& sf, V3 wi ) {
+    if ( !glass_is_sampled ( sf, wi ) ) return v3 ( 0, 0, 0 );
+    float k = sf.attr[3].x / dot ( sf.normal, wi );
+    return sf.attr[0] * k;
+}
+
 TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
     if ( sf.bsdf == kDevBsdfPhong ) return phong_sample ( sf, e1, e2, e3, wo );
+    if ( sf.bsdf == kDevBsdfGGX ) return ggx_sample ( sf, e1, e2, wo );
+    if ( sf.bsdf == kDevBsdfGlass ) return glass_sample ( sf, e3, wo );
     return diffuse_sample ( sf, e1, e2 );
 }
 TD float bsdf_pdf ( const Surface& sf, V3 wi, V3 wo ) {
     if ( sf.bsdf == kDevBsdfPhong ) return phong_pdf ( sf, wi, wo );
+    if ( sf.bsdf == kDevBsdfGGX ) return ggx_pdf ( sf, wi, wo );
+    if ( sf.bsdf == kDevBsdfGlass ) return glass_pdf ( sf, wi );
     return diffuse_pdf ( sf, wi );
 }
 TD V3 bsdf_eval ( const Surface& sf, V3 wi, V3 wo ) {
     if ( sf.bsdf == kDevBsdfPhong ) return phong_eval ( sf, wi, wo );
+    if ( sf.bsdf == kDevBsdfGGX ) return ggx_eval ( sf, wi, wo );
+    if ( sf.bsdf == kDevBsdfGlass ) return glass_eval ( sf, wi );
     return diffuse_eval ( sf );
 }
 

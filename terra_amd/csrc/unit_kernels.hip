@@ -165,7 +165,7 @@ __global__ void k_bsdf ( int kind, int n, float* surfaces47, const float* e3, co
     // the tangent frame is a function of the normal (terra_f4x4_basis); q[0..15] is not read
     sf.normal = v3p ( q + 16 ); sf.emissive = v3p ( q + 19 );
     for ( int a = 0; a < 4; ++a ) sf.attr[a] = v3p ( q + 23 + 3 * a );
-    sf.bsdf = kind;
+    sf.bsdf = kind; sf.ior = q[22];
     V3 wo = v3p ( wo3 + 3 * i );
     V3 wi = bsdf_sample ( sf, e3[3 * i], e3[3 * i + 1], e3[3 * i + 2], wo );
     float p = bsdf_pdf ( sf, wi, wo );
@@ -173,7 +173,7 @@ __global__ void k_bsdf ( int kind, int n, float* surfaces47, const float* e3, co
     wi3[3 * i] = wi.x; wi3[3 * i + 1] = wi.y; wi3[3 * i + 2] = wi.z;
     pdf[i] = p;
     f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
-    q[23 + 9] = sf.attr[3].x;
+    q[23 + 6] = sf.attr[2].x; q[23 + 7] = sf.attr[2].y; q[23 + 8] = sf.attr[2].z; q[23 + 9] = sf.attr[3].x;
 }
 hipError_t terra_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, const float* wo3, float* wi3, float* pdf, float* f3 ) {
     hipLaunchKernelGGL ( k_bsdf, UNIT_GRID ( n ), 0, 0, kind, n, surfaces47, e3, wo3, wi3, pdf, f3 );

@@ -22,7 +22,8 @@ FRAME_SEED = 0x5EED0001
 
 @dataclass
 class Material:
-    kind: str = "diffuse"                 # "diffuse" | "phong"
+    kind: str = "diffuse"                 # "diffuse" | "phong" | "ggx" | "glass" (the last two: this repo's own presets)
+    roughness: float = 0.2
     albedo: tuple = (0.73, 0.73, 0.73)
     emissive: tuple = (0.0, 0.0, 0.0)
     specular_color: tuple = (0.0, 0.0, 0.0)
@@ -137,6 +138,38 @@ def cornell_phong(width=256, height=256, spp=4, bounces=8, integrator=api.kTerra
     d.objects[4].material = Material(kind="phong", albedo=(0.35, 0.35, 0.35), specular_color=(0.6, 0.6, 0.6), specular_intensity=40.0)
     d.objects[5].material = Material(kind="phong", albedo=(0.10, 0.20, 0.45), specular_color=(0.5, 0.5, 0.5), specular_intensity=8.0)
     d.name = "cornell32_phong"
+    return d
+
+
+def _uv_sphere(center, radius, n=32):
+    """n x n UV sphere (n a power of two), outward vertex normals, libm-free; 2*n*n - 2*n triangles"""
+    c2, s2 = _unit_circle(2 * n)                 # latitude: k*pi/n, k = 0..n
+    lat_c, lat_s = c2[: n + 1].copy(), s2[: n + 1].copy()
+    lat_c[n], lat_s[n] = -1.0, 0.0
+    lon_c, lon_s = _unit_circle(n)
+    lon_c = np.append(lon_c, lon_c[0]); lon_s = np.append(lon_s, lon_s[0])
+    N = np.stack([lat_s[:, None] * lon_c[None, :], np.broadcast_to(lat_c[:, None], (n + 1, n + 1)), lat_s[:, None] * lon_s[None, :]], axis=-1)
+    P = np.asarray(center, np.float64) + radius * N
+    tris, nrm = _grid(P, N)
+    e1 = tris[:, 1] - tris[:, 0]; e2 = tris[:, 2] - tris[:, 0]
+    keep = (np.cross(e1, e2) ** 2).sum(axis=1) > 0          # drop the degenerate triangles at the poles
+    return tris[keep], nrm[keep], np.zeros((int(keep.sum()), 3, 2), np.float32)
+
+
+def cornell_spheres(width=1920, height=1080, spp=1024, bounces=8, integrator=api.kTerraIntegratorSimple, **kw) -> SceneDesc:
+    """BASELINE.json configs[3] / SURVEY.md section 8d 'Config 4': Cornell-32 with the two boxes replaced
+    in place by a glass sphere (ior 1.5) and a GGX metal sphere (alpha 0.2), ~2k triangles each.
+    Both BSDFs are this repo's own definitions (no runnable reference: SURVEY.md A14)."""
+    d = cornell_box(width, height, spp, bounces, integrator)
+    glass = _uv_sphere((0.45, 0.45, -0.35), 0.4)
+    metal = _uv_sphere((-0.45, 0.5, 0.35), 0.5)
+    d.objects = d.objects[:4] + [
+        ObjectDesc(*glass, Material(kind="glass", albedo=(0.98, 0.98, 0.98), ior=1.5), "glass_sphere"),
+        ObjectDesc(*metal, Material(kind="ggx", specular_color=(0.95, 0.78, 0.45), roughness=0.2), "metal_sphere"),
+    ]
+    d.name = "cornell_spheres"
+    for k, v in kw.items():
+        setattr(d, k, v)
     return d
 
 
@@ -320,6 +353,17 @@ def fill_object(lib: api.TerraLib, obj: api.TerraObject, od: ObjectDesc) -> None
         mat.attributes[api.TERRA_PHONG_SAMPLE_PICK] = api.const_attribute(lib, (0.0, 0.0, 0.0))
         mat.attributes_count = api.TERRA_PHONG_END
         lib.bsdf_phong_init(C.byref(mat.bsdf))
+    elif m.kind == "ggx":
+        mat.attributes[api.TERRA_GGX_F0] = api.const_attribute(lib, m.specular_color)
+        mat.attributes[api.TERRA_GGX_ROUGHNESS] = api.const_attribute(lib, (m.roughness,) * 3)
+        mat.attributes_count = api.TERRA_GGX_END
+        lib.bsdf_ggx_init(C.byref(mat.bsdf))
+    elif m.kind == "glass":
+        mat.attributes[api.TERRA_GLASS_TINT] = api.const_attribute(lib, m.albedo)
+        for slot in (api.TERRA_GLASS_UNUSED, api.TERRA_GLASS_SAMPLE_DIR, api.TERRA_GLASS_SAMPLE_PROB):
+            mat.attributes[slot] = api.const_attribute(lib, (0.0, 0.0, 0.0))
+        mat.attributes_count = api.TERRA_GLASS_END
+        lib.bsdf_glass_init(C.byref(mat.bsdf))
     else:
         raise ValueError(f"unknown material kind {m.kind!r}")
 

@@ -223,7 +223,7 @@ class Unit:
             assert rc == 0, last_error()
             return wi, pdf, f, surf
         b = api.TerraBSDF()
-        (self.L.bsdf_diffuse_init if kind_id == 0 else self.L.bsdf_phong_init)(C.byref(b))
+        [self.L.bsdf_diffuse_init, self.L.bsdf_phong_init, getattr(self.L, "bsdf_ggx_init", None), getattr(self.L, "bsdf_glass_init", None)][kind_id](C.byref(b))
         SP = C.POINTER(api.TerraShadingSurface)
         fs = C.CFUNCTYPE(api.TerraFloat3, SP, c_f, c_f, c_f, F3P)(b.sample)
         fp = C.CFUNCTYPE(c_f, SP, F3P, F3P)(b.pdf)
@@ -432,6 +432,12 @@ def bsdf_cases(seed, n, kind_id):
     surf[:, 22] = 1.5
     if kind_id == 0:
         surf[:, 23:26] = r.uniform(0, 1, size=(n, 3))
+    elif kind_id == 2:      # GGX: F0, roughness
+        surf[:, 23:26] = r.uniform(0.2, 1, size=(n, 3))
+        surf[:, 26:29] = r.uniform(0.02, 0.9, size=(n, 1))
+    elif kind_id == 3:      # glass: tint, ior in slot 22, scratch slots zero
+        surf[:, 23:26] = r.uniform(0.5, 1, size=(n, 3))
+        surf[:, 22] = r.uniform(1.1, 2.4, size=n)
     else:
         surf[:, 23:26] = r.uniform(0, 1, size=(n, 3))       # specular colour
         surf[:, 26:29] = r.uniform(0, 1, size=(n, 3))       # albedo
@@ -439,6 +445,8 @@ def bsdf_cases(seed, n, kind_id):
     e = (r.randint(0, 2 ** 24, size=(n, 3)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
     wo = unit_dirs(r, n)
     flip = np.einsum("nc,nc->n", wo, nrm) < 0
+    if kind_id == 3:
+        flip[n // 2:] = ~flip[n // 2:]          # glass: half of the cases arrive from inside the medium
     wo[flip] = -wo[flip]
     return np.ascontiguousarray(surf), np.ascontiguousarray(e), np.ascontiguousarray(wo)
 

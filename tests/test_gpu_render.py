@@ -272,6 +272,7 @@ def test_full_hd_properties(H, L, orc_lib, devmath_mode):
 def test_hall_100k_goldens(H, L):
     g = G(H, "render_hall")
     d = scenes.sponza_hall(64, 36, 1)
+    L.clear_error()
     scene = scenes.build_scene(L, d)
     assert runtime.last_error() == "", runtime.last_error()
     U = H.Unit("amd")
