@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--workload", default="cornell_1080p_512spp")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
+    ap.add_argument("--check", action="store_true", help="after timing: one sharded+gathered pass on a cleared frame must equal an unsharded pass bit for bit (rank 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,13 +135,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
+    ngpu = torch.cuda.device_count()
+    if ngpu < 1:
+        raise SystemExit("bench.py needs an MI355X")
+    dev_index = (local_rank % ngpu) if world > 1 else 0        # ranks > GPUs only happens in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", dev_index)
+    via_host = world > 1 and args.dist_backend != "nccl"
 
     lib = runtime.load()
     if lib.device_count() <= 0:
@@ -169,7 +177,15 @@ def main():
             ev[i][1].record()
         if world > 1:
             runtime.check(lib.pack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, packed.data_ptr(), stream), "pack")
-            dist.gather(packed, gather_list=gather_bufs, dst=0)
+            if via_host:
+                torch.cuda.synchronize(dev)
+                hb = [torch.zeros(n_packed, dtype=torch.float32) for _ in range(world)] if rank == 0 else None
+                dist.gather(packed.cpu(), gather_list=hb, dst=0)
+                if rank == 0:
+                    for src in range(1, world):
+                        gather_bufs[src].copy_(hb[src])
+            else:
+                dist.gather(packed, gather_list=gather_bufs, dst=0)
             if rank == 0:
                 for src in range(1, world):
                     runtime.check(lib.unpack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, src, world, gather_bufs[src].data_ptr(), stream), "unpack")
@@ -193,6 +209,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    check = None
+    if args.check:
+        fb.clear(); fence(); step(); fence()
+        if rank == 0:
+            ref_fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
+            runtime.check(lib.render_device(C.byref(cam), scene, ref_fb.pixels.data_ptr(), ref_fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, stream), "render")
+            torch.cuda.synchronize(dev)
+            check = bool(torch.equal(ref_fb.pixels.view(torch.int32), fb.pixels.view(torch.int32)) and torch.equal(ref_fb.results, fb.results))
     st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     frame_samples = d.width * d.height * d.spp
@@ -218,6 +242,10 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg), "rank0_only": world > 1},
             "counters_per_launch": {k: v // max(1, st["launches"]) for k, v in st.items() if k != "launches"},
         }
+        if check is not None:
+            out["sharded_equals_unsharded"] = check
+        if world > 1:
+            out["dist_backend"] = args.dist_backend
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
         print(json.dumps(out), flush=True)
