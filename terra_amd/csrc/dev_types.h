@@ -109,7 +109,11 @@ struct DevRenderParams {
     unsigned long long* counters;   // kCtrCount entries
     // LDS plan of a block (host decides, kernel obeys): stack_depth stack entries per thread,
     // lds_nodes nodes (breadth-first prefix) and lds_tris triangles (+ their vertex properties)
-    // staged; leaf_cap deferred-leaf entries per thread; lds_mode 0 = nothing staged, 1 = whole scene, 2 = node prefix only
+    // staged; leaf_cap deferred-leaf entries per thread; lds_mode 0 = nothing staged, 1 = whole scene
     uint32_t stack_depth, leaf_cap, lds_nodes, lds_tris;
     int32_t  lds_mode;
+    // lean counting (COUNT level 1): attribute fetches per hit (attributes_count + 1, identical for every material)
+    uint32_t lean_attr_per_hit;
+    int32_t  count_level;           // 1 lean, 2 full (see trace_device.h randf)
+    uint32_t bsdf_kinds;            // mask of DevBsdfKind present in the scene (bit k = kind k)
 };

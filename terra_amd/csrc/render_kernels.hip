@@ -20,21 +20,31 @@
 
 struct DevResult { float acc[3]; int samples; };
 
-TD void wave_flush_counters ( const Counters& c, unsigned long long* g ) {
+template <int COUNT>
+TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t lean_attr_per_hit ) {
     const uint32_t v[6] = { c.rays, c.nodes, c.tri_tests, c.hits, c.rand_calls, c.attr_fetches };
     const int slot[6] = { kCtrRays, kCtrNodes, kCtrTriTests, kCtrHits, kCtrRandCalls, kCtrAttrFetches };
     #pragma unroll
-    for ( int k = 0; k < 6; ++k ) {
+    for ( int k = 0; k < ( COUNT == 2 ? 6 : 4 ); ++k ) {
         unsigned long long x = v[k];
         #pragma unroll
         for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
-        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &g[slot[k]], x );
+        if ( ( threadIdx.x & 63 ) == 0 && x ) {
+            atomicAdd ( &g[slot[k]], x );
+            if ( COUNT == 1 && k == 3 ) {       // lean: 4 stream-B draws and a fixed number of attribute fetches per hit
+                atomicAdd ( &g[kCtrRandCalls], 4 * x );
+                atomicAdd ( &g[kCtrAttrFetches], ( unsigned long long ) lean_attr_per_hit * x );
+            }
+        }
     }
 }
 
 // Builds the block's Tracer: carves the dynamic LDS, stages the scene prefix the host
 // planned (DevRenderParams.lds_*), and leaves every thread with its own stack / leaf
 // list column. Called by all 256 threads (it contains the block barrier).
+// per-thread words parked in LDS between uses (indexed [word][thread] like the stack): the pixel's
+// radiance sum of this call, touched once per path
+#define TERRA_AUX_WORDS 3
 TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
     const int tid = threadIdx.x;
     Tracer T;
@@ -44,7 +54,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.leaves = words + stack_depth * 256 + tid;
     T.stride = 256;
     T.leaf_cap = ( int ) leaf_cap;
-    float4* stage = lds + ( stack_depth + leaf_cap ) * 64;
+    float4* stage = lds + ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 64;
     float4* ln = stage;
     float4* lt = ln + 4 * lds_nodes;
     float4* lp = lt + 3 * lds_tris;
@@ -70,7 +80,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
 #define TERRA_WAVES_LIGHT 4
 #endif
 #define TERRA_WAVES_FOR(I) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : TERRA_WAVES_SIMPLE )
-template <int INTEGRATOR, bool COUNT, int MODE>
+template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
@@ -95,7 +105,9 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_
     PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples );
     Counters c = counters_zero();
 
-    V3 acc = v3 ( 0, 0, 0 ), Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
+    float* acc_lds = reinterpret_cast<float*> ( lds_f4 ) + ( p.stack_depth + p.leaf_cap ) * 256 + tid;     // acc.x/y/z at [0], [256], [512]
+    acc_lds[0] = 0.f; acc_lds[256] = 0.f; acc_lds[512] = 0.f;
+    V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     Ray ray = make_ray ( v3 ( 0, 0, 0 ), v3 ( 0, 0, 1 ) );
     uint32_t s = 0, bounce = 0;
     bool alive = false;
@@ -113,11 +125,11 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_
         bool end = !h.hit;
         if ( h.hit ) {
             V3 wo = neg ( ray.d );
-            Lo = Lo + integrate<INTEGRATOR, COUNT, MODE> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
+            Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
             float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
-            V3 wi = bsdf_sample ( sf, e0, e1, e2, wo );
-            float pdf = sel_max ( bsdf_pdf ( sf, wi, wo ), ( float ) 1e-4 );
-            V3 f = bsdf_eval ( sf, wi, wo ) * ( 1.f / pdf );
+            V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+            float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
+            V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
             throughput = had ( throughput, f );
             throughput = throughput * dot ( sf.normal, wi );
             float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
@@ -131,23 +143,23 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_
                 end = bounce > p.bounces;
             }
         }
-        if ( end ) { acc = acc + Lo; alive = false; }
+        if ( end ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; alive = false; }
     }
 
     if ( valid ) {
         const size_t pix = ( size_t ) py * p.fb_w + px;
         const DevResult prior = results[pix];
         DevResult out;
-        out.acc[0] = acc.x + prior.acc[0]; out.acc[1] = acc.y + prior.acc[1]; out.acc[2] = acc.z + prior.acc[2];
+        out.acc[0] = acc_lds[0] + prior.acc[0]; out.acc[1] = acc_lds[256] + prior.acc[1]; out.acc[2] = acc_lds[512] + prior.acc[2];
         out.samples = prior.samples + ( int ) p.spp;
         results[pix] = out;
         float n = ( float ) out.samples;
         V3 color = v3 ( out.acc[0] / n, out.acc[1] / n, out.acc[2] / n ) * p.exposure;
         color = tonemap ( color, p.tonemap, p.gamma );
         p.pixels[3 * pix + 0] = color.x; p.pixels[3 * pix + 1] = color.y; p.pixels[3 * pix + 2] = color.z;
-        if ( p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
+        if ( COUNT == 2 && p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
     }
-    if ( COUNT ) wave_flush_counters ( c, p.counters );
+    if ( COUNT ) wave_flush_counters<COUNT> ( c, p.counters, p.lean_attr_per_hit );
 }
 
 // ---- launch -------------------------------------------------------------------
@@ -158,7 +170,7 @@ static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank
 }
 
 size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
-    return ( size_t ) ( stack_depth + leaf_cap ) * 1024 + ( size_t ) lds_nodes * 64 + ( size_t ) lds_tris * ( 48 + 64 );
+    return ( size_t ) ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) lds_nodes * 64 + ( size_t ) lds_tris * ( 48 + 64 );
 }
 
 // LDS plan. Small scenes (whole scene <= budget): stage everything; with the Cornell box that is
@@ -176,25 +188,26 @@ void terra_plan_lds ( DevRenderParams& p ) {
     p.stack_depth = depth;
     p.leaf_cap = TERRA_LEAF_CAP_MAX;
     size_t whole = ( size_t ) p.scene.n_nodes * 64 + ( size_t ) p.scene.n_tris * 112;
-    if ( ( size_t ) ( depth + TERRA_LEAF_CAP_MAX ) * 1024 + whole <= budget ) {
+    if ( ( size_t ) ( depth + TERRA_LEAF_CAP_MAX + TERRA_AUX_WORDS ) * 1024 + whole <= budget ) {
         p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris;
     } else {
         p.lds_mode = 0; p.lds_nodes = 0; p.lds_tris = 0;
     }
 }
 
-template <int I, int MODE>
-static hipError_t launch_mode ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
-    hipLaunchKernelGGL ( ( terra_render_kernel<I, true, MODE> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
+template <int I, int MODE, int KINDS>
+static hipError_t launch_kinds ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
+    // lean counting is only valid for integrators without light sampling (every hit = 4 draws)
+    constexpr bool lean_ok = I == 0 || I == 3 || I == 4 || I == 5;
+    if ( lean_ok && p.count_level == 1 ) hipLaunchKernelGGL ( ( terra_render_kernel<I, lean_ok ? 1 : 2, MODE, KINDS> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
+    else hipLaunchKernelGGL ( ( terra_render_kernel<I, 2, MODE, KINDS> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
     return hipGetLastError();
 }
 template <int I>
 static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
-    switch ( p.lds_mode ) {
-        case 1: return launch_mode<I, 1> ( p, blocks, lds, stream );
-        case 2: return launch_mode<I, 2> ( p, blocks, lds, stream );
-        default: return launch_mode<I, 0> ( p, blocks, lds, stream );
-    }
+    const bool diffuse_only = p.bsdf_kinds == 1;
+    if ( p.lds_mode == 1 ) return diffuse_only ? launch_kinds<I, 1, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 1, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
+    return diffuse_only ? launch_kinds<I, 0, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 0, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
 }
 
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {

@@ -235,6 +235,8 @@ struct Scene {
     DevScene dev; void* d_blob = nullptr; size_t d_bytes = 0;
     unsigned long long* d_counters = nullptr;
     uint64_t launches = 0, stat_pixels = 0, stat_samples = 0;
+    int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
+    uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
     std::string commit_error;
 };
 
@@ -440,6 +442,10 @@ static int upload_scene ( Scene* s ) {
         d.first_tri = s->first_tri[j]; d.tri_count = ( uint32_t ) s->objects[j].triangles_count;
         d.emissive[0] = m.emissive.value.x; d.emissive[1] = m.emissive.value.y; d.emissive[2] = m.emissive.value.z;
     }
+    s->uniform_attr_count = nobj ? ( int ) mats[0].attributes_count : -1;
+    for ( size_t j = 1; j < nobj; ++j ) if ( ( int ) mats[j].attributes_count != s->uniform_attr_count ) s->uniform_attr_count = -1;
+    s->bsdf_kinds = 0;
+    for ( size_t j = 0; j < nobj; ++j ) s->bsdf_kinds |= 1u << mats[j].bsdf;
     // flatten
     std::vector<DevTri> tris ( ntri ? ntri : 1 );
     std::vector<DevProps> props ( ntri ? ntri : 1 );
@@ -625,6 +631,10 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.frame_seed = s->frame_seed;
     p.counters = s->d_counters;
     terra_plan_lds ( p );
+    // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
+    p.bsdf_kinds = s->bsdf_kinds;
+    p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;
+    p.lean_attr_per_hit = s->uniform_attr_count >= 0 ? ( uint32_t ) s->uniform_attr_count + 1 : 0;
     return 0;
 }
 
@@ -651,6 +661,7 @@ extern "C" int terra_amd_render_device_sharded ( const TerraCamera* cam, HTerraS
     if ( rc ) return rc;
     if ( !d_pixels || !d_results ) return fail ( kTerraAmdErrBadArgument, "null framebuffer pointer" );
     p.pixels = ( float* ) d_pixels; p.results = d_results; p.rand_calls = ( uint32_t* ) d_rand_calls;
+    if ( d_rand_calls ) p.count_level = 2;
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     HIP_TRY ( terra_launch_render ( p, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
     account_launch ( s, p );

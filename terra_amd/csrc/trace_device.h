@@ -184,7 +184,7 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 //
 // LDS layout of a block (DESIGN.md "LDS"): [node stack: stack_depth x 256 ints]
 // [leaf list: leaf_cap x 256 ints] [staged nodes: lds_nodes x 64 B]
-// [staged triangles: lds_tris x 48 B] [staged vertex properties: lds_tris x 64 B].
+// [per-thread parked words] [staged triangles: lds_tris x 48 B] [staged vertex properties: lds_tris x 64 B].
 // Stack and leaf list are indexed [entry][thread] so the 64 lanes of a wave touch
 // 64 consecutive words (conflict free). Device node numbering is breadth first, so
 // the staged prefix [0, lds_nodes) is the top of the tree; triangles are staged only
@@ -275,12 +275,11 @@ TD bool watertight_permuted ( const float pa[3], const float pb[3], const float 
 //     strict "<" on depth, selects the same triangle;
 //   * when a lane's list is full the lists are drained and the node loop resumes;
 //   * the hit point is formed once, from the winning depth (same expression).
-// MODE 0: nodes/triangles from global memory; 1: everything staged in LDS;
-// 2: staged node prefix, triangles global.
+// MODE 0: nodes/triangles from global memory; 1: everything staged in LDS.
 // -----------------------------------------------------------------------------
 struct Closest { float depth; uint32_t tri; };
 
-template <bool COUNT, int MODE, bool FAST>
+template <int COUNT, int MODE, bool FAST>
 TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
     const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
     const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
@@ -291,7 +290,7 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
         while ( top > 0 && nleaf <= T.leaf_cap - 2 ) {
             uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
             float4 q0, q1, q2, q3;
-            if ( MODE == 1 || ( MODE == 2 && ni < T.lds_nodes ) ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
+            if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
             else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
             uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
             if ( COUNT ) ++c.nodes;
@@ -327,7 +326,7 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     }
 }
 
-template <bool COUNT, int MODE>
+template <int COUNT, int MODE>
 TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
     Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
@@ -388,7 +387,7 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
 
 struct RaycastResult { bool hit; uint32_t object, tri_in_object, tri; V3 point; };
 
-template <bool COUNT, int MODE>
+template <int COUNT, int MODE>
 TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Counters& c ) {
     Ray r = in;
     r.o = r.o + r.d * 0.001f;
@@ -400,7 +399,8 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
     if ( res.hit ) {
         uint32_t nattr;
         surface_init<MODE> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
-        if ( COUNT ) { ++c.hits; c.attr_fetches += nattr + 1; }
+        if ( COUNT ) ++c.hits;
+        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
     }
     return res;
 }
@@ -549,35 +549,45 @@ TD V3 glass_eval ( const Surface& sf, V3 wi ) {
     return sf.attr[0] * k;
 }
 
+// BSDF dispatch. KINDS is a compile-time mask of the preset kinds present in the committed scene
+// (bit k = DevBsdfKind k): a diffuse-only scene compiles to straight-line diffuse code, which is
+// what keeps the Simple kernel inside 96 VGPRs (5 waves/SIMD) without scratch.
+#define TERRA_KINDS_ALL 15
+template <int KINDS>
 TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
-    if ( sf.bsdf == kDevBsdfPhong ) return phong_sample ( sf, e1, e2, e3, wo );
-    if ( sf.bsdf == kDevBsdfGGX ) return ggx_sample ( sf, e1, e2, wo );
-    if ( sf.bsdf == kDevBsdfGlass ) return glass_sample ( sf, e3, wo );
+    if ( ( KINDS & 2 ) && ( KINDS == 2 || sf.bsdf == kDevBsdfPhong ) ) return phong_sample ( sf, e1, e2, e3, wo );
+    if ( ( KINDS & 4 ) && ( KINDS == 4 || sf.bsdf == kDevBsdfGGX ) ) return ggx_sample ( sf, e1, e2, wo );
+    if ( ( KINDS & 8 ) && ( KINDS == 8 || sf.bsdf == kDevBsdfGlass ) ) return glass_sample ( sf, e3, wo );
     return diffuse_sample ( sf, e1, e2 );
 }
+template <int KINDS>
 TD float bsdf_pdf ( const Surface& sf, V3 wi, V3 wo ) {
-    if ( sf.bsdf == kDevBsdfPhong ) return phong_pdf ( sf, wi, wo );
-    if ( sf.bsdf == kDevBsdfGGX ) return ggx_pdf ( sf, wi, wo );
-    if ( sf.bsdf == kDevBsdfGlass ) return glass_pdf ( sf, wi );
+    if ( ( KINDS & 2 ) && ( KINDS == 2 || sf.bsdf == kDevBsdfPhong ) ) return phong_pdf ( sf, wi, wo );
+    if ( ( KINDS & 4 ) && ( KINDS == 4 || sf.bsdf == kDevBsdfGGX ) ) return ggx_pdf ( sf, wi, wo );
+    if ( ( KINDS & 8 ) && ( KINDS == 8 || sf.bsdf == kDevBsdfGlass ) ) return glass_pdf ( sf, wi );
     return diffuse_pdf ( sf, wi );
 }
+template <int KINDS>
 TD V3 bsdf_eval ( const Surface& sf, V3 wi, V3 wo ) {
-    if ( sf.bsdf == kDevBsdfPhong ) return phong_eval ( sf, wi, wo );
-    if ( sf.bsdf == kDevBsdfGGX ) return ggx_eval ( sf, wi, wo );
-    if ( sf.bsdf == kDevBsdfGlass ) return glass_eval ( sf, wi );
+    if ( ( KINDS & 2 ) && ( KINDS == 2 || sf.bsdf == kDevBsdfPhong ) ) return phong_eval ( sf, wi, wo );
+    if ( ( KINDS & 4 ) && ( KINDS == 4 || sf.bsdf == kDevBsdfGGX ) ) return ggx_eval ( sf, wi, wo );
+    if ( ( KINDS & 8 ) && ( KINDS == 8 || sf.bsdf == kDevBsdfGlass ) ) return glass_eval ( sf, wi );
     return diffuse_eval ( sf );
 }
 
 // -----------------------------------------------------------------------------
 // lights and integrators
 // -----------------------------------------------------------------------------
-TD float randf ( Pcg32& b, Counters& c, bool count ) { if ( count ) ++c.rand_calls; return trng_b_float ( b ); }
+// COUNT levels: 0 none; 1 lean = rays, nodes, tri_tests, hits per lane (draws and attribute fetches are then
+// derived from hits at flush time, valid when every hit is a main-path hit with 4 draws and all materials have the
+// same attribute count); 2 full = all six per lane
+TD float randf ( Pcg32& b, Counters& c, int count ) { if ( count == 2 ) ++c.rand_calls; return trng_b_float ( b ); }
 
 TD float triangle_area ( V3 a, V3 b, V3 cc ) { return length ( cross ( b - a, cc - a ) ) / 2; }
 
 struct LightSample { uint32_t light_object; uint32_t tri_in_object; uint32_t tri; float pick_pdf; V3 pos, norm; };
 
-template <bool COUNT>
+template <int COUNT>
 TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c ) {
     LightSample ls;
     float e = ( float ) ( ( double ) randf ( rb, c, COUNT ) - 1e-4 );
@@ -602,7 +612,7 @@ TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c ) 
     return ls;
 }
 
-template <bool COUNT, int MODE>
+template <int COUNT, int MODE, int KINDS>
 TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
@@ -616,7 +626,7 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
     if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
         float cosv = dot ( neg ( wi ), ls.norm );
         if ( cosv > 0 ) {
-            V3 f = bsdf_eval ( sf, wi, wo );
+            V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
             float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[h.tri] );
             V3 Ld = had ( lsf.emissive, f );
             Ld = Ld * ( dot ( wi, sf.normal ) / ( pdf * ls.pick_pdf ) );
@@ -626,14 +636,14 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
     return had ( Lo, throughput );
 }
 
-template <bool COUNT, int MODE, bool DEBUG_WEIGHTS>
+template <int COUNT, int MODE, int KINDS, bool DEBUG_WEIGHTS>
 TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
     if ( DEBUG_WEIGHTS ) { if ( bounce != 0 ) return Lo; }
     else if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
     float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT ), e3 = randf ( rb, c, COUNT );
-    V3 bsdf_dir = bsdf_sample ( sf, e1, e2, e3, wo );
+    V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo );
     LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
     {
         V3 p_to_light = ls.pos - p;
@@ -644,7 +654,7 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
         if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
             float cosv = dot ( ls.norm, neg ( wi ) );
             if ( cosv > 0 ) {
-                float bpdf = bsdf_pdf ( sf, wi, wo );
+                float bpdf = bsdf_pdf<KINDS> ( sf, wi, wo );
                 float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[h.tri] );
                 if ( DEBUG_WEIGHTS ) {
                     float weight = ( bpdf * bpdf ) / ( lpdf * lpdf + bpdf * bpdf );
@@ -652,7 +662,7 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
                 } else {
                     float weight = ( lpdf * lpdf ) / ( lpdf * lpdf + bpdf * bpdf );
                     if ( lpdf != 0 ) {
-                        V3 f = bsdf_eval ( sf, wi, wo );
+                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
                         V3 L = had ( lsf.emissive, f );
                         L = L * ( dot ( wi, sf.normal ) * weight / ( lpdf * ls.pick_pdf ) );
                         Lo = Lo + L;
@@ -663,8 +673,8 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
     }
     {
         V3 wi = bsdf_dir;
-        V3 f = bsdf_eval ( sf, wi, wo );
-        float bpdf = bsdf_pdf ( sf, wi, wo );
+        V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
+        float bpdf = bsdf_pdf<KINDS> ( sf, wi, wo );
         V3 light_wo = neg ( wi );
         Surface lsf;
         Ray r = surface_ray ( sf, p, wi, 1.f );
@@ -709,15 +719,15 @@ TD V3 integrate_debug_normals ( const Surface& sf, uint32_t bounce ) {
 }
 
 // integrator ids = TerraIntegrator (reference include/Terra.h:149-157)
-template <int INTEGRATOR, bool COUNT, int MODE>
+template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 TD V3 integrate ( const Tracer& T, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     if ( INTEGRATOR == 0 ) {
         if ( dot ( wo, sf.normal ) > 0 ) return had ( sf.emissive, throughput );
         return v3 ( 0, 0, 0 );
     } else if ( INTEGRATOR == 1 ) {
-        return integrate_direct<COUNT, MODE> ( T, sf, p, wo, throughput, bounce, rb, c );
+        return integrate_direct<COUNT, MODE, KINDS> ( T, sf, p, wo, throughput, bounce, rb, c );
     } else if ( INTEGRATOR == 2 ) {
-        return integrate_mis<COUNT, MODE, false> ( T, sf, p, wo, throughput, bounce, rb, c );
+        return integrate_mis<COUNT, MODE, KINDS, false> ( T, sf, p, wo, throughput, bounce, rb, c );
     } else if ( INTEGRATOR == 3 ) {
         return bounce != 0 ? v3 ( 0, 0, 0 ) : v3 ( 1, 1, 1 );
     } else if ( INTEGRATOR == 4 ) {
@@ -727,7 +737,7 @@ TD V3 integrate ( const Tracer& T, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 
     } else if ( INTEGRATOR == 5 ) {
         return integrate_debug_normals ( sf, bounce );
     } else {
-        return integrate_mis<COUNT, MODE, true> ( T, sf, p, wo, throughput, bounce, rb, c );
+        return integrate_mis<COUNT, MODE, KINDS, true> ( T, sf, p, wo, throughput, bounce, rb, c );
     }
 }
 
@@ -735,7 +745,7 @@ TD V3 integrate ( const Tracer& T, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 
 // one full path (the reference's terra_trace), used by the unit entry point and,
 // restructured with path regeneration, by the render kernel
 // -----------------------------------------------------------------------------
-template <int INTEGRATOR, bool COUNT, int MODE>
+template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counters& c ) {
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     for ( uint32_t bounce = 0; bounce <= bounces; ++bounce ) {
@@ -743,11 +753,11 @@ TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counte
         RaycastResult h = scene_raycast<COUNT, MODE> ( T, ray, sf, c );
         if ( !h.hit ) break;
         V3 wo = neg ( ray.d );
-        Lo = Lo + integrate<INTEGRATOR, COUNT, MODE> ( T, ray, sf, h.point, wo, throughput, bounce, rb, c );
+        Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rb, c );
         float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
-        V3 wi = bsdf_sample ( sf, e0, e1, e2, wo );
-        float pdf = sel_max ( bsdf_pdf ( sf, wi, wo ), ( float ) 1e-4 );
-        V3 f = bsdf_eval ( sf, wi, wo ) * ( 1.f / pdf );
+        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
+        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
         throughput = had ( throughput, f );
         throughput = throughput * dot ( sf.normal, wi );
         float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );

@@ -88,7 +88,7 @@ __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, c
     RayState s = ray_state_init ( r );
     Counters c = counters_zero();
     Tracer T = unit_tracer ( sc, lds_stack );
-    Closest b = bvh_traverse<false, 0> ( T, r, s, c );
+    Closest b = bvh_traverse<0, 0> ( T, r, s, c );
     bool f = b.tri != 0xffffffffu;
     found[i] = f ? 1 : 0;
     prim[i] = f ? ( sc.tris[b.tri].object | ( sc.tris[b.tri].tri_in_object << 8 ) ) : 0u;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__ ( 256 ) void k_raycast ( DevScene sc, int n, const 
     Counters c = counters_zero();
     Surface sf;
     Tracer T = unit_tracer ( sc, lds_stack );
-    RaycastResult h = scene_raycast<false, 0> ( T, r, sf, c );
+    RaycastResult h = scene_raycast<0, 0> ( T, r, sf, c );
     obj[i] = h.hit ? ( int ) h.object : -1;
     tri[i] = h.hit ? ( int ) h.tri_in_object : 0;
     point[3 * i] = h.point.x; point[3 * i + 1] = h.point.y; point[3 * i + 2] = h.point.z;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__ ( 256 ) void k_trace ( DevScene sc, uint32_t bounce
     Pcg32 b; b.state = stateB[i]; b.inc = incB[i];
     Counters c = counters_zero();
     Tracer T = unit_tracer ( sc, lds_stack );
-    V3 L = trace_path<I, true, 0> ( T, r, bounces, b, c );
+    V3 L = trace_path<I, 2, 0, TERRA_KINDS_ALL> ( T, r, bounces, b, c );
     radiance[3 * i] = L.x; radiance[3 * i + 1] = L.y; radiance[3 * i + 2] = L.z;
     rand_calls[i] = c.rand_calls;
 }
@@ -167,9 +167,9 @@ __global__ void k_bsdf ( int kind, int n, float* surfaces47, const float* e3, co
     for ( int a = 0; a < 4; ++a ) sf.attr[a] = v3p ( q + 23 + 3 * a );
     sf.bsdf = kind; sf.ior = q[22];
     V3 wo = v3p ( wo3 + 3 * i );
-    V3 wi = bsdf_sample ( sf, e3[3 * i], e3[3 * i + 1], e3[3 * i + 2], wo );
-    float p = bsdf_pdf ( sf, wi, wo );
-    V3 f = bsdf_eval ( sf, wi, wo );
+    V3 wi = bsdf_sample<TERRA_KINDS_ALL> ( sf, e3[3 * i], e3[3 * i + 1], e3[3 * i + 2], wo );
+    float p = bsdf_pdf<TERRA_KINDS_ALL> ( sf, wi, wo );
+    V3 f = bsdf_eval<TERRA_KINDS_ALL> ( sf, wi, wo );
     wi3[3 * i] = wi.x; wi3[3 * i + 1] = wi.y; wi3[3 * i + 2] = wi.z;
     pdf[i] = p;
     f3[3 * i] = f.x; f3[3 * i + 1] = f.y; f3[3 * i + 2] = f.z;
