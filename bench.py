@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
+    ap.add_argument("--tree", default="reference", choices=["reference", "fast"], help="reference = the reference's own tree and traversal order (parity mode, the headline); fast = terra_amd_set_tree_mode(1)")
     ap.add_argument("--check", action="store_true", help="after timing: one sharded+gathered pass on a cleared frame must equal an unsharded pass bit for bit (rank 0)")
     args = ap.parse_args()
 
@@ -155,7 +156,7 @@ def main():
     runtime.check(lib.set_device(dev.index), "terra_amd_set_device")
 
     d = workload(args.workload, args.spp)
-    scene = scenes.build_scene(lib, d)
+    scene = scenes.build_scene(lib, d, tree_mode=1 if args.tree == "fast" else 0)
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
     cam = scenes.camera_of(d)
@@ -235,7 +236,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces,
                        "integrator": "simple" if d.integrator == 0 else ("direct" if d.integrator == 1 else str(d.integrator)),
-                       "triangles": d.triangle_count, "tile": TILE, "parallelism": f"tiles%{world}" if world > 1 else "single"},
+                       "triangles": d.triangle_count, "tree": args.tree, "tile": TILE, "parallelism": f"tiles%{world}" if world > 1 else "single"},
             "mrays_per_s": round(st["rays"] / max(1, st["launches"]) * (1 if world == 1 else world) / (kernel_ms * 1e-3) / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3),

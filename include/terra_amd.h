@@ -47,6 +47,14 @@ int  terra_amd_get_device ( void );
 void     terra_amd_set_frame_seed ( HTerraScene scene, uint64_t seed );
 uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
 
+/* Accelerator used by subsequent commits. 0 (default) = the reference's own tree (X-only sweep SAH,
+   src/TerraBVH.c:79-244) traversed in the reference's order: the parity mode. 1 = "fast tree": a
+   3-axis binned-SAH BVH2 over the same triangles with ordered, culled traversal; ties in depth are
+   resolved by the reference tree's leaf visit order, so it selects the same triangle as mode 0
+   (DESIGN.md "Fast tree"). Takes effect at the next terra_scene_commit(). */
+int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
+int  terra_amd_get_tree_mode ( HTerraScene scene );
+
 /* Work counters of the device path, summed over all launches since the last
    reset. They define the algorithmic bytes of the roofline:
    bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels. */

@@ -80,6 +80,13 @@ struct DevScene {
     uint32_t n_nodes, n_tris, n_objects, n_lights;
     uint32_t lights_triangles_count;
     int32_t  max_stack;
+    // optional second accelerator over the same triangles (terra_amd_set_tree_mode, DESIGN.md "Fast tree"):
+    // 3-axis binned-SAH BVH2, leaves of up to 4 triangles; fast_tris is the soup in leaf order with
+    // DevTri::pad = the triangle's rank in the REFERENCE tree's leaf visit order (the tie-break key)
+    const DevNode*     fast_nodes;
+    const DevTri*      fast_tris;
+    uint32_t n_fast_nodes;
+    int32_t  fast_max_stack;
 };
 
 // indices into the device counter array (uint64 each); mirrors TerraAmdStats

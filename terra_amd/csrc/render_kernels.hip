@@ -174,11 +174,15 @@ size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_n
 }
 
 // LDS plan. Small scenes (whole scene <= budget): stage everything; with the Cornell box that is
-// 27.5 KB per block, so the 5 blocks/CU the Simple kernel's registers allow stay resident.
+// 30.5 KB per block, so the 5 blocks/CU the Simple kernel's registers allow stay resident.
 // Large scenes: nothing is staged -- their node fetches are bound by the L1 tag rate of divergent
-// 16-byte loads (each lane its own 64-B node), a staged prefix of ~100 nodes does not change that,
-// and a full-size leaf list (fewer drain phases) measured faster than the extra block of occupancy
-// a shorter list would buy (gpurun_out/ab4.log: 219 ms at 16 entries vs 228 ms at 10, 261 ms at 4).
+// 16-byte loads (each lane its own 64-B node) and by latency, so resident blocks matter most: the
+// leaf list takes what is left of the CU's 160 KB after fitting as many blocks as possible while
+// keeping at least 8 entries (gpurun_out/ab4.log, ab5.log: 4 blocks x 14 entries 219 ms vs
+// 3 blocks x 16 entries 305 ms vs 4-entry lists 261 ms on the 97k-triangle hall).
+#ifndef TERRA_LDS_CU_KB
+#define TERRA_LDS_CU_KB 158
+#endif
 #ifndef TERRA_LDS_BUDGET
 #define TERRA_LDS_BUDGET ( 32 * 1024 )
 #endif
@@ -190,8 +194,12 @@ void terra_plan_lds ( DevRenderParams& p ) {
     size_t whole = ( size_t ) p.scene.n_nodes * 64 + ( size_t ) p.scene.n_tris * 112;
     if ( ( size_t ) ( depth + TERRA_LEAF_CAP_MAX + TERRA_AUX_WORDS ) * 1024 + whole <= budget ) {
         p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris;
-    } else {
-        p.lds_mode = 0; p.lds_nodes = 0; p.lds_tris = 0;
+        return;
+    }
+    p.lds_mode = 0; p.lds_nodes = 0; p.lds_tris = 0;
+    for ( int blocks = 5; blocks >= 1; --blocks ) {
+        int room = TERRA_LDS_CU_KB / blocks - ( int ) depth - TERRA_AUX_WORDS;       // KB per block left for the leaf list (2 KB of slack per CU)
+        if ( room >= 8 || blocks == 1 ) { p.leaf_cap = ( uint32_t ) ( room > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : ( room < 4 ? 4 : room ) ); break; }
     }
 }
 
@@ -207,6 +215,7 @@ template <int I>
 static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
     const bool diffuse_only = p.bsdf_kinds == 1;
     if ( p.lds_mode == 1 ) return diffuse_only ? launch_kinds<I, 1, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 1, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
+    if ( p.lds_mode == 2 ) return diffuse_only ? launch_kinds<I, 2, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 2, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
     return diffuse_only ? launch_kinds<I, 0, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 0, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
 }
 

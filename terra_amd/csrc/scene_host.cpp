@@ -237,6 +237,8 @@ struct Scene {
     uint64_t launches = 0, stat_pixels = 0, stat_samples = 0;
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
+    int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree (terra_amd_set_tree_mode)
+    int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
 };
 
@@ -266,6 +268,13 @@ extern "C" TerraObject* terra_scene_add_object ( HTerraScene h, size_t n ) {
 }
 extern "C" size_t terra_scene_count_objects ( HTerraScene h ) { return S ( h )->objects_pop; }
 extern "C" TerraSceneOptions* terra_scene_get_options ( HTerraScene h ) { return &S ( h )->new_opts; }
+extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
+    if ( mode != 0 && mode != 1 ) return fail ( kTerraAmdErrBadArgument, "tree mode %d (0 = reference tree, 1 = fast tree)", mode );
+    Scene* s = S ( h );
+    if ( s->tree_mode != mode ) { s->tree_mode = mode; s->dirty_objects = true; s->committed = false; }
+    return 0;
+}
+extern "C" int terra_amd_get_tree_mode ( HTerraScene h ) { return S ( h )->tree_mode; }
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
 extern "C" uint64_t terra_amd_get_frame_seed ( HTerraScene h ) { return S ( h )->frame_seed; }
 
@@ -402,6 +411,112 @@ static void build ( const TerraObject* objects, size_t nobj, std::vector<HostNod
 }
 } // namespace bvh
 
+// ---- fast tree: 3-axis binned SAH, BVH2, leaves of <= 4 triangles ----------
+// Built over the same per-triangle boxes as the reference (triangle bounds +- 1e-4) so every
+// triangle a ray can hit lies inside its ancestors' boxes; inner boxes are plain unions.
+namespace fastbvh {
+struct Prim { TerraAABB box; float c[3]; uint32_t soup; };
+struct Built { std::vector<DevNode> nodes; std::vector<uint32_t> order; int max_stack = 1; };
+
+static inline void grow ( TerraAABB& b, const TerraAABB& o ) {
+    b.min.x = std::min ( b.min.x, o.min.x ); b.min.y = std::min ( b.min.y, o.min.y ); b.min.z = std::min ( b.min.z, o.min.z );
+    b.max.x = std::max ( b.max.x, o.max.x ); b.max.y = std::max ( b.max.y, o.max.y ); b.max.z = std::max ( b.max.z, o.max.z );
+}
+static inline float half_area ( const TerraAABB& b ) {
+    float w = b.max.x - b.min.x, h = b.max.y - b.min.y, d = b.max.z - b.min.z;
+    return w * h + h * d + d * w;
+}
+static TerraAABB empty() { return bvh::empty_box(); }
+
+// returns the child word for the range [lo, hi) of prims, appending nodes as needed
+static uint32_t build_range ( std::vector<Prim>& prims, int lo, int hi, Built& out, int depth, int& max_depth );
+
+static uint32_t make_leaf ( int lo, int hi ) { return DEV_CHILD_LEAF | ( ( uint32_t ) ( hi - lo - 1 ) << 27 ) | ( uint32_t ) lo; }
+
+static void set_child ( DevNode& n, int k, const TerraAABB& b, uint32_t word ) {
+    float* mn = k == 0 ? n.min0 : n.min1; float* mx = k == 0 ? n.max0 : n.max1;
+    mn[0] = b.min.x; mn[1] = b.min.y; mn[2] = b.min.z; mx[0] = b.max.x; mx[1] = b.max.y; mx[2] = b.max.z;
+    n.child[k] = word; n.prim[k] = 0;
+}
+
+static Built build ( std::vector<Prim>& prims ) {
+    Built out;
+    const int n = ( int ) prims.size();
+    out.nodes.reserve ( ( size_t ) std::max ( 1, n ) );
+    out.nodes.push_back ( DevNode() );
+    memset ( &out.nodes[0], 0, sizeof ( DevNode ) );
+    struct Task { int lo, hi, node, slot, depth; };
+    // root node holds the whole scene as (child0 = everything, child1 = empty) unless it splits
+    std::vector<Task> todo;
+    int max_depth = 1;
+    auto bounds = [&] ( int lo, int hi ) { TerraAABB b = empty(); for ( int i = lo; i < hi; ++i ) grow ( b, prims[i].box ); return b; };
+    auto split = [&] ( int lo, int hi, int& mid ) -> bool {
+        const int cnt = hi - lo;
+        if ( cnt <= 4 ) return false;
+        float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        for ( int i = lo; i < hi; ++i ) for ( int a = 0; a < 3; ++a ) { cmin[a] = std::min ( cmin[a], prims[i].c[a] ); cmax[a] = std::max ( cmax[a], prims[i].c[a] ); }
+        const int B = 16;
+        float best_cost = FLT_MAX; int best_axis = -1, best_bin = -1;
+        for ( int a = 0; a < 3; ++a ) {
+            float ext = cmax[a] - cmin[a];
+            if ( ! ( ext > 0.f ) ) continue;
+            TerraAABB bb[B]; int bc[B];
+            for ( int b = 0; b < B; ++b ) { bb[b] = empty(); bc[b] = 0; }
+            const float scale = ( float ) B / ext;
+            for ( int i = lo; i < hi; ++i ) { int b = std::min ( B - 1, std::max ( 0, ( int ) ( ( prims[i].c[a] - cmin[a] ) * scale ) ) ); grow ( bb[b], prims[i].box ); ++bc[b]; }
+            float la[B], ra[B]; int lc[B], rc[B];
+            TerraAABB acc = empty(); int cacc = 0;
+            for ( int b = 0; b < B; ++b ) { grow ( acc, bb[b] ); cacc += bc[b]; la[b] = cacc ? half_area ( acc ) : 0.f; lc[b] = cacc; }
+            acc = empty(); cacc = 0;
+            for ( int b = B - 1; b >= 0; --b ) { grow ( acc, bb[b] ); cacc += bc[b]; ra[b] = cacc ? half_area ( acc ) : 0.f; rc[b] = cacc; }
+            for ( int b = 0; b < B - 1; ++b ) {
+                if ( lc[b] == 0 || rc[b + 1] == 0 ) continue;
+                float cost = la[b] * ( float ) lc[b] + ra[b + 1] * ( float ) rc[b + 1];
+                if ( cost < best_cost ) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        if ( best_axis < 0 ) {      // all centroids coincide: split in the middle
+            mid = lo + cnt / 2;
+            return true;
+        }
+        const float ext = cmax[best_axis] - cmin[best_axis], scale = ( float ) B / ext, c0 = cmin[best_axis];
+        const int a = best_axis, bsel = best_bin;
+        auto it = std::partition ( prims.begin() + lo, prims.begin() + hi, [&] ( const Prim & p ) {
+            int b = std::min ( B - 1, std::max ( 0, ( int ) ( ( p.c[a] - c0 ) * scale ) ) ); return b <= bsel; } );
+        mid = ( int ) ( it - prims.begin() );
+        if ( mid == lo || mid == hi ) mid = lo + cnt / 2;
+        return true;
+    };
+    if ( n == 0 ) { out.nodes[0].child[0] = DEV_CHILD_EMPTY; out.nodes[0].child[1] = DEV_CHILD_EMPTY; out.max_stack = 1; return out; }
+    int mid = 0;
+    if ( !split ( 0, n, mid ) ) {
+        set_child ( out.nodes[0], 0, bounds ( 0, n ), make_leaf ( 0, n ) );
+        out.nodes[0].child[1] = DEV_CHILD_EMPTY;
+        out.max_stack = 1;
+    } else {
+        todo.push_back ( { 0, mid, 0, 0, 1 } );
+        todo.push_back ( { mid, n, 0, 1, 1 } );
+        while ( !todo.empty() ) {
+            Task t = todo.back(); todo.pop_back();
+            max_depth = std::max ( max_depth, t.depth );
+            TerraAABB b = bounds ( t.lo, t.hi );
+            int m = 0;
+            if ( !split ( t.lo, t.hi, m ) ) { set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, make_leaf ( t.lo, t.hi ) ); continue; }
+            uint32_t idx = ( uint32_t ) out.nodes.size();
+            out.nodes.push_back ( DevNode() );
+            memset ( &out.nodes.back(), 0, sizeof ( DevNode ) );
+            set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, idx );
+            todo.push_back ( { t.lo, m, ( int ) idx, 0, t.depth + 1 } );
+            todo.push_back ( { m, t.hi, ( int ) idx, 1, t.depth + 1 } );
+        }
+        out.max_stack = max_depth + 2;     // ordered traversal: at most one extra pending entry per level
+    }
+    out.order.resize ( ( size_t ) n );
+    for ( int i = 0; i < n; ++i ) out.order[ ( size_t ) i] = prims[ ( size_t ) i].soup;
+    return out;
+}
+} // namespace fastbvh
+
 static float triangle_area ( const TerraTriangle& t ) {
     TerraFloat3 ab = terra_subf3 ( &t.b, &t.a ), ac = terra_subf3 ( &t.c, &t.a );
     TerraFloat3 c = terra_crossf3 ( &ab, &ac );
@@ -490,11 +605,41 @@ static int upload_scene ( Scene* s ) {
             } else { d.child[c] = DEV_CHILD_EMPTY; d.prim[c] = 0; }
         }
     }
+    // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
+    std::vector<DevNode> fnodes; std::vector<DevTri> ftris;
+    s->fast_nodes = 0; s->fast_max_stack = 1;
+    if ( s->tree_mode == 1 ) {
+        // rank of every soup triangle in the reference traversal's leaf visit order (all boxes hit)
+        std::vector<uint32_t> rank ( ntri ? ntri : 1, 0 );
+        {
+            uint32_t next = 0; std::vector<int> st; st.push_back ( 0 );
+            while ( !st.empty() ) {
+                const HostNode& h = s->nodes[ ( size_t ) st.back()]; st.pop_back();
+                for ( int c = 0; c < 2; ++c ) {
+                    if ( h.type[c] == 1 ) { uint32_t obj = ( uint32_t ) h.index[c] & 0xffu, tri = ( uint32_t ) h.index[c] >> 8; rank[s->first_tri[obj] + tri] = next++; }
+                    else if ( h.type[c] == -1 ) st.push_back ( h.index[c] );
+                }
+            }
+        }
+        std::vector<fastbvh::Prim> prims ( ntri );
+        for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count; ++i ) {
+            fastbvh::Prim& q = prims[s->first_tri[j] + i];
+            q.box = bvh::empty_box(); bvh::grow_by_triangle ( q.box, s->objects[j].triangles[i] );
+            q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
+            q.soup = ( uint32_t ) ( s->first_tri[j] + i );
+        }
+        fastbvh::Built built = fastbvh::build ( prims );
+        fnodes.swap ( built.nodes );
+        ftris.resize ( ntri ? ntri : 1 );
+        for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
+        s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
+    }
     // one blob, 256-byte aligned sections
     auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
     size_t o_mats = align ( o_props + props.size() * sizeof ( DevProps ) ), o_lights = align ( o_mats + mats.size() * sizeof ( DevMaterial ) );
-    size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), total = align ( o_area + tri_area.size() * sizeof ( float ) );
+    size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
+    size_t o_ft = align ( o_fn + fnodes.size() * sizeof ( DevNode ) ), total = align ( o_ft + ftris.size() * sizeof ( DevTri ) );
 
     release_device ( s );
     s->device = g_device;
@@ -510,11 +655,17 @@ static int upload_scene ( Scene* s ) {
     HIP_TRY ( hipMemcpy ( base + o_mats, mats.data(), mats.size() * sizeof ( DevMaterial ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( base + o_lights, lights.data(), lights.size() * sizeof ( DevLight ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( base + o_area, tri_area.data(), tri_area.size() * sizeof ( float ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    if ( !fnodes.empty() ) {
+        HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    }
     s->d_bytes = total;
     s->dev.nodes = ( const DevNode* ) ( base + o_nodes ); s->dev.tris = ( const DevTri* ) ( base + o_tris ); s->dev.props = ( const DevProps* ) ( base + o_props );
     s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
     s->dev.n_nodes = ( uint32_t ) nodes.size(); s->dev.n_tris = ( uint32_t ) ntri; s->dev.n_objects = ( uint32_t ) nobj; s->dev.n_lights = ( uint32_t ) s->lights.size();
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
+    s->dev.fast_nodes = fnodes.empty() ? nullptr : ( const DevNode* ) ( base + o_fn ); s->dev.fast_tris = fnodes.empty() ? nullptr : ( const DevTri* ) ( base + o_ft );
+    s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
     s->device_ok = true;
     return 0;
 }
@@ -631,6 +782,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.frame_seed = s->frame_seed;
     p.counters = s->d_counters;
     terra_plan_lds ( p );
+    if ( s->tree_mode == 1 && s->dev.fast_nodes ) { p.lds_mode = 2; p.lds_nodes = 0; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) s->dev.fast_max_stack; }
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;
     p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;

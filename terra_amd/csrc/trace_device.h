@@ -337,6 +337,77 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 }
 
 // -----------------------------------------------------------------------------
+// MODE 2: traversal of the optional fast tree (DESIGN.md "Fast tree"). Not the reference's
+// traversal: near child first, subtrees whose entry distance exceeds the closest hit are
+// culled, leaves hold up to 4 triangles. It returns the reference's answer because the
+// reference's closest hit is order independent once ties are resolved the way its fixed
+// leaf visit order resolves them: smallest depth, then smallest reference visit rank
+// (DevTri::pad of the fast soup). The triangle test itself is the same arithmetic.
+// Child word of a fast node: bit 31 leaf; leaf = (count-1) << 27 | first triangle.
+// -----------------------------------------------------------------------------
+TD bool slab_enter ( V3 bmin, V3 bmax, const Ray& r, float& t_enter ) {
+    float t1x = ( bmin.x - r.o.x ) * r.inv.x, t2x = ( bmax.x - r.o.x ) * r.inv.x;
+    float t1y = ( bmin.y - r.o.y ) * r.inv.y, t2y = ( bmax.y - r.o.y ) * r.inv.y;
+    float t1z = ( bmin.z - r.o.z ) * r.inv.z, t2z = ( bmax.z - r.o.z ) * r.inv.z;
+    float tmin = sel_min ( t1x, t2x ), tmax = sel_max ( t1x, t2x );
+    tmin = sel_max ( tmin, sel_min ( t1y, t2y ) ); tmax = sel_min ( tmax, sel_max ( t1y, t2y ) );
+    tmin = sel_max ( tmin, sel_min ( t1z, t2z ) ); tmax = sel_min ( tmax, sel_max ( t1z, t2z ) );
+    t_enter = sel_max ( tmin, 0.f );
+    return tmax > t_enter;
+}
+
+struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
+
+template <int COUNT>
+TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
+    const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
+    const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
+    ClosestRanked best; best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
+    V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+    int top = 1;
+    T.stack[0] = 0;
+    while ( top > 0 ) {
+        uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+        float4 q0 = nodes[4 * ni], q1 = nodes[4 * ni + 1], q2 = nodes[4 * ni + 2], q3 = nodes[4 * ni + 3];
+        uint32_t child[2] = { __float_as_uint ( q3.x ), __float_as_uint ( q3.y ) };
+        if ( COUNT ) ++c.nodes;
+        float te[2];
+        bool hit[2];
+        hit[0] = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te[0] ) && te[0] <= best.depth && child[0] != DEV_CHILD_EMPTY;
+        hit[1] = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te[1] ) && te[1] <= best.depth && child[1] != DEV_CHILD_EMPTY;
+        #pragma unroll
+        for ( int k = 0; k < 2; ++k ) {
+            if ( hit[k] && ( child[k] & DEV_CHILD_LEAF ) ) {
+                uint32_t first = child[k] & 0x07ffffffu, cnt = ( ( child[k] >> 27 ) & 0xfu ) + 1;
+                for ( uint32_t j = 0; j < cnt; ++j ) {
+                    uint32_t ti = first + j;
+                    float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
+                    V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+                    float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
+                    float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
+                    float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
+                    if ( COUNT ) ++c.tri_tests;
+                    float depth;
+                    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
+                        uint32_t rank = __float_as_uint ( cc.w );
+                        if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
+                    }
+                }
+            }
+        }
+        bool in0 = hit[0] && ! ( child[0] & DEV_CHILD_LEAF ), in1 = hit[1] && ! ( child[1] & DEV_CHILD_LEAF );
+        // far child first, so the near one is popped next
+        if ( in0 && in1 ) {
+            bool zero_near = te[0] <= te[1];
+            T.stack[top * T.stride] = ( int ) ( zero_near ? child[1] : child[0] ); ++top;
+            T.stack[top * T.stride] = ( int ) ( zero_near ? child[0] : child[1] ); ++top;
+        } else if ( in0 ) { T.stack[top * T.stride] = ( int ) child[0]; ++top; }
+        else if ( in1 ) { T.stack[top * T.stride] = ( int ) child[1]; ++top; }
+    }
+    return best;
+}
+
+// -----------------------------------------------------------------------------
 // surface
 // -----------------------------------------------------------------------------
 // The reference also stores the tangent frame (terra_f4x4_basis of the normal) in the
@@ -358,10 +429,12 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
         t0 = lt[3 * ti]; t1 = lt[3 * ti + 1]; t2 = lt[3 * ti + 2];
         p0 = T.l_props[4 * ti]; p1 = T.l_props[4 * ti + 1]; p2 = T.l_props[4 * ti + 2];
     } else {
-        const float4* tris = reinterpret_cast<const float4*> ( T.sc.tris );
+        const float4* tris = reinterpret_cast<const float4*> ( MODE == 2 ? T.sc.fast_tris : T.sc.tris );
         const float4* props = reinterpret_cast<const float4*> ( T.sc.props );
         t0 = tris[3 * ti]; t1 = tris[3 * ti + 1]; t2 = tris[3 * ti + 2];
-        p0 = props[4 * ti]; p1 = props[4 * ti + 1]; p2 = props[4 * ti + 2];
+        uint32_t pi = ti;
+        if ( MODE == 2 ) pi = T.sc.mats[__float_as_uint ( t0.w )].first_tri + __float_as_uint ( t1.w );
+        p0 = props[4 * pi]; p1 = props[4 * pi + 1]; p2 = props[4 * pi + 2];
     }
     V3 ta = v3 ( t0.x, t0.y, t0.z ), tb = v3 ( t1.x, t1.y, t1.z ), tc = v3 ( t2.x, t2.y, t2.z );
     uint32_t object = __float_as_uint ( t0.w );
@@ -393,12 +466,15 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
     r.o = r.o + r.d * 0.001f;
     RayState st = ray_state_init ( r );
     if ( COUNT ) ++c.rays;
-    Closest best = bvh_traverse<COUNT, MODE> ( T, r, st, c );
+    Closest best;
+    if ( MODE == 2 ) { ClosestRanked b2 = bvh_traverse_fast<COUNT> ( T, r, st, c ); best.depth = b2.depth; best.tri = b2.tri; }
+    else best = bvh_traverse<COUNT, MODE> ( T, r, st, c );
     RaycastResult res; res.hit = best.tri != 0xffffffffu; res.tri = best.tri; res.object = 0; res.tri_in_object = 0;
     res.point = res.hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
     if ( res.hit ) {
         uint32_t nattr;
         surface_init<MODE> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
+        if ( MODE == 2 ) res.tri = T.sc.mats[res.object].first_tri + res.tri_in_object;      // back to the soup index (lights, areas)
         if ( COUNT ) ++c.hits;
         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
     }

@@ -383,9 +383,13 @@ def apply_options(lib: api.TerraLib, scene, d: SceneDesc) -> None:
     o.gamma = d.gamma
 
 
-def build_scene(lib: api.TerraLib, d: SceneDesc):
-    """Returns a committed HTerraScene (c_void_p value) owned by `lib`."""
+def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode: int = 0):
+    """Returns a committed HTerraScene (c_void_p value) owned by `lib`.
+    tree_mode 1 selects the product's fast tree (terra_amd_set_tree_mode); the reference and the oracle only have mode 0."""
     scene = lib.scene_create()
+    if tree_mode:
+        f = lib.fn("terra_amd_set_tree_mode", C.c_int, [C.c_void_p, C.c_int])
+        assert f(scene, tree_mode) == 0
     for od in d.objects:
         obj = lib.scene_add_object(scene, len(od.triangles)).contents
         fill_object(lib, obj, od)

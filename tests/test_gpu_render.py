@@ -47,9 +47,9 @@ def render_host(L, d, passes=1, rects=None, threads=False, seed=None):
     return out
 
 
-def render_dev(L, d, passes=1, rect=None, calls=False, shard=None):
+def render_dev(L, d, passes=1, rect=None, calls=False, shard=None, tree_mode=0):
     import torch
-    scene = scenes.build_scene(L, d)
+    scene = scenes.build_scene(L, d, tree_mode=tree_mode)
     fb = runtime.DeviceFramebuffer(d.width, d.height)
     cam = scenes.camera_of(d)
     rc = torch.zeros(d.width * d.height, dtype=torch.int32, device="cuda") if calls else None
@@ -300,3 +300,58 @@ def test_hall_full_hd_crop_vs_oracle_and_tiles(H, L, orc_lib, devmath_mode):
     part = render_dev(L, d, rect=(960, 512, 192, 128))
     assert H.same_bits(part["pixels"][512:640, 960:1152], full["pixels"][512:640, 960:1152])
     assert full["stats"]["samples"] == 1920 * 1080 * 2
+
+
+# ---------------------------------------------------------------------------
+# fast tree (terra_amd_set_tree_mode(1)): different tree and traversal order, same image
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,integ", [("cornell", 0), ("cornell", 2), ("phong", 1), ("spheres", 2), ("hall", 0), ("hall", 1), ("soup", 2)])
+def test_fast_tree_selects_the_same_hits(H, L, name, integ):
+    if name == "cornell":
+        d = scenes.cornell_box(96, 64, 4, integrator=integ)
+    elif name == "phong":
+        d = scenes.cornell_phong(96, 64, 3, integrator=integ)
+    elif name == "spheres":
+        d = scenes.cornell_spheres(96, 64, 3, integrator=integ)
+    elif name == "hall":
+        d = scenes.sponza_hall(160, 90, 2, integrator=integ)
+    else:
+        from test_oracle_vs_reference import soup_scene
+        d = soup_scene(H, 2000, 21, integrator=integ); d.width, d.height, d.spp = 80, 48, 3
+    a = render_dev(L, d, calls=True, passes=2)
+    b = render_dev(L, d, calls=True, passes=2, tree_mode=1)
+    assert np.array_equal(a["rand_calls"], b["rand_calls"])
+    assert same(H, a["pixels"], b["pixels"]) and same(H, a["acc"], b["acc"])
+    assert b["stats"]["nodes"] < a["stats"]["nodes"] or name in ("cornell", "phong")
+
+
+def test_fast_tree_hall_goldens_and_work(H, L):
+    """the fast tree reproduces the REFERENCE's image of the 97k-triangle hall with a fraction of the traversal work"""
+    g = G(H, "render_hall")
+    out = render_dev(L, scenes.sponza_hall(160, 90, 2, integrator=0), calls=True, tree_mode=1)
+    assert H.same_bits(out["pixels"], g["i0_pixels"]) and np.array_equal(out["rand_calls"], g["i0_calls"].astype(np.uint32))
+    ref = render_dev(L, scenes.sponza_hall(160, 90, 2, integrator=0))
+    assert out["stats"]["nodes"] * 4 < ref["stats"]["nodes"]
+
+
+# ---------------------------------------------------------------------------
+# the work counters behind Mrays/s and the roofline's algorithmic bytes (SURVEY.md 8d)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,integ", [("cornell", 0), ("cornell", 1), ("phong", 2), ("hall", 0)])
+def test_device_work_counters_equal_the_oracles(H, L, orc_lib, devmath_mode, name, integ):
+    import ctypes as C
+    d = {"cornell": scenes.cornell_box, "phong": scenes.cornell_phong}.get(name, None)
+    d = d(80, 56, 3, integrator=integ) if d else scenes.sponza_hall(48, 27, 1, integrator=integ)
+    got = render_dev(L, d)["stats"]
+
+    class Ctr(C.Structure):
+        _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "box_tests", "tri_tests", "hits", "samples", "rand_calls", "attr_fetches")]
+    orc_lib.fn("orc_counters_reset", None, [])()
+    H.Unit("orc").render_pixels(d, want_calls=False)
+    c = Ctr(); orc_lib.fn("orc_counters_get", None, [C.POINTER(Ctr)])(C.byref(c))
+    want = {n: int(getattr(c, n)) for n, _ in Ctr._fields_}
+    for k in want:
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert got["pixels"] == d.width * d.height and got["launches"] == 1
