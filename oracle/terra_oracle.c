@@ -175,7 +175,12 @@ TerraFloat3 orc_texture_read ( TerraTexture* t, size_t x, size_t y ) {      /* r
         case kTerraTextureAddressWrap:  x %= W; y %= H; break;
         default: /* mirror */
             if ( ( x / W ) % 2 == 0 ) { x %= W; y %= H; }
-            else { x = W - ( x % W ); y = H - ( y % H ); }
+            else {  /* the reference's mirror branch yields x == W / y == H (one past the end) whenever x%W == 0 / y%H == 0
+                       (src/Terra.c:385-386): clamped here, as in the product */
+                x = W - ( x % W ); y = H - ( y % H );
+                if ( x > W - 1 ) x = W - 1;
+                if ( y > H - 1 ) y = H - 1;
+            }
             break;
     }
     if ( t->depth == 1 ) {

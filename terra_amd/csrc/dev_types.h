@@ -53,6 +53,17 @@ static_assert ( sizeof ( DevProps ) == 64, "DevProps must be 64 bytes" );
 
 enum DevBsdfKind { kDevBsdfDiffuse = 0, kDevBsdfPhong = 1, kDevBsdfGGX = 2, kDevBsdfGlass = 3 };
 
+// A texture as the reference samples it (reference src/Terra.c:368-466): texel-space lookups,
+// 1-byte (x/255) or float components, point or bilinear filter, wrap / mirror / clamp addressing.
+struct DevTexture {
+    const void* data;              // HBM copy of TerraTexture::pixels (+ 2 elements of padding)
+    uint32_t width, height;
+    uint32_t components;
+    uint32_t depth;                // 1 or 4 bytes per component
+    uint32_t filter;               // TerraFilter
+    uint32_t address_mode;         // TerraTextureAddressMode
+};
+
 struct DevMaterial {
     int32_t  bsdf;                 // DevBsdfKind
     uint32_t attributes_count;
@@ -61,6 +72,9 @@ struct DevMaterial {
     float    emissive[3];
     uint32_t tri_count;
     float    attributes[TERRA_DEV_MAX_ATTR][3];
+    // texture index per attribute slot (slot TERRA_DEV_MAX_ATTR = emissive), -1 = the constant above
+    int32_t  tex[TERRA_DEV_MAX_ATTR + 1];
+    int32_t  any_texture;
 };
 
 struct DevLight {
@@ -77,6 +91,7 @@ struct DevScene {
     const DevMaterial* mats;
     const DevLight*    lights;
     const float*       tri_area;
+    const DevTexture*  textures;
     uint32_t n_nodes, n_tris, n_objects, n_lights;
     uint32_t lights_triangles_count;
     int32_t  max_stack;

@@ -536,6 +536,7 @@ static int upload_scene ( Scene* s ) {
     s->first_tri.assign ( nobj, 0 );
     for ( size_t j = 0; j < nobj; ++j ) { s->first_tri[j] = ( uint32_t ) ntri; ntri += s->objects[j].triangles_count; }
     if ( ntri >= 0x7fffffffu ) return fail ( kTerraAmdErrUnsupported, "too many triangles" );
+    std::vector<const TerraTexture*> textures;
     std::vector<DevMaterial> mats ( nobj ? nobj : 1 );
     memset ( mats.data(), 0, mats.size() * sizeof ( DevMaterial ) );
     for ( size_t j = 0; j < nobj; ++j ) {
@@ -547,9 +548,25 @@ static int upload_scene ( Scene* s ) {
         else if ( is_glass ( m.bsdf ) ) d.bsdf = kDevBsdfGlass;
         else return fail ( kTerraAmdErrUnsupported, "object %zu: BSDF function pointers are not a terra_bsdf_*_init preset of this library; host callbacks cannot run on the device", j );
         if ( m.attributes_count > TERRA_MATERIAL_MAX_ATTRIBUTES ) return fail ( kTerraAmdErrBadArgument, "object %zu: attributes_count %zu > %d", j, m.attributes_count, TERRA_MATERIAL_MAX_ATTRIBUTES );
-        if ( m.emissive.state != nullptr ) return fail ( kTerraAmdErrUnsupported, "object %zu: textured emissive is not supported on the device yet", j );
+        for ( int a = 0; a <= TERRA_DEV_MAX_ATTR; ++a ) d.tex[a] = -1;
+        d.any_texture = 0;
+        // an attribute is a constant (state == NULL) or a texture sampled with this library's terra_texture_sample
+        // (reference src/Terra.c:294-298, 1804-1810); anything else is a host callback the device cannot run
+        auto bind = [&] ( const TerraAttribute & at, int slot, const char* what ) -> int {
+            if ( at.state == nullptr ) return 0;
+            if ( at.eval != terra_texture_sample ) return fail ( kTerraAmdErrUnsupported, "object %zu %s: attribute callbacks other than terra_texture_sample cannot run on the device (lat-long lookups of a material attribute read past the texcoord in the reference, src/Terra.c:468-471)", j, what );
+            const TerraTexture* t = ( const TerraTexture* ) at.state;
+            if ( !t->pixels || !t->width || !t->height || ( t->depth != 1 && t->depth != 4 ) || t->components == 0 ) return fail ( kTerraAmdErrBadArgument, "object %zu %s: invalid texture", j, what );
+            size_t k = 0;
+            for ( ; k < textures.size(); ++k ) if ( textures[k] == t ) break;
+            if ( k == textures.size() ) textures.push_back ( t );
+            d.tex[slot] = ( int32_t ) k; d.any_texture = 1;
+            return 0;
+        };
+        if ( int rc = bind ( m.emissive, TERRA_DEV_MAX_ATTR, "emissive" ) ) return rc;
         for ( size_t a = 0; a < m.attributes_count; ++a ) {
-            if ( m.attributes[a].state != nullptr ) return fail ( kTerraAmdErrUnsupported, "object %zu attribute %zu: textured/procedural attributes are not supported on the device yet", j, a );
+            char what[32]; snprintf ( what, sizeof what, "attribute %zu", a );
+            if ( int rc = bind ( m.attributes[a], ( int ) a, what ) ) return rc;
             d.attributes[a][0] = m.attributes[a].value.x; d.attributes[a][1] = m.attributes[a].value.y; d.attributes[a][2] = m.attributes[a].value.z;
         }
         d.attributes_count = ( uint32_t ) m.attributes_count;
@@ -639,13 +656,22 @@ static int upload_scene ( Scene* s ) {
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
     size_t o_mats = align ( o_props + props.size() * sizeof ( DevProps ) ), o_lights = align ( o_mats + mats.size() * sizeof ( DevMaterial ) );
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
-    size_t o_ft = align ( o_fn + fnodes.size() * sizeof ( DevNode ) ), total = align ( o_ft + ftris.size() * sizeof ( DevTri ) );
+    size_t o_ft = align ( o_fn + fnodes.size() * sizeof ( DevNode ) ), o_td = align ( o_ft + ftris.size() * sizeof ( DevTri ) );
+    std::vector<DevTexture> tdesc ( textures.size() );
+    std::vector<size_t> tex_off ( textures.size() );
+    size_t total = align ( o_td + tdesc.size() * sizeof ( DevTexture ) );
+    for ( size_t k = 0; k < textures.size(); ++k ) {
+        const TerraTexture* t = textures[k];
+        tex_off[k] = total;
+        total = align ( total + ( ( size_t ) t->width * t->height * t->components + 2 ) * t->depth );      // +2 elements: the 3-component read of the last texel
+    }
 
     release_device ( s );
     s->device = g_device;
     if ( terra_amd_device_count() <= 0 ) return fail ( kTerraAmdErrNoDevice, "no HIP device visible: terra_scene_commit built the host tree but cannot upload; terra_render will fail" );
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMalloc ( &s->d_blob, total ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemset ( s->d_blob, 0, total ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMalloc ( ( void** ) &s->d_counters, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemset ( s->d_counters, 0, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
     char* base = ( char* ) s->d_blob;
@@ -659,6 +685,14 @@ static int upload_scene ( Scene* s ) {
         HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
+    for ( size_t k = 0; k < textures.size(); ++k ) {
+        const TerraTexture* t = textures[k];
+        HIP_TRY ( hipMemcpy ( base + tex_off[k], t->pixels, ( size_t ) t->width * t->height * t->components * t->depth, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        tdesc[k].data = base + tex_off[k]; tdesc[k].width = t->width; tdesc[k].height = t->height; tdesc[k].components = t->components;
+        tdesc[k].depth = t->depth; tdesc[k].filter = t->filter; tdesc[k].address_mode = t->address_mode;
+    }
+    if ( !tdesc.empty() ) HIP_TRY ( hipMemcpy ( base + o_td, tdesc.data(), tdesc.size() * sizeof ( DevTexture ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    s->dev.textures = tdesc.empty() ? nullptr : ( const DevTexture* ) ( base + o_td );
     s->d_bytes = total;
     s->dev.nodes = ( const DevNode* ) ( base + o_nodes ); s->dev.tris = ( const DevTri* ) ( base + o_tris ); s->dev.props = ( const DevProps* ) ( base + o_props );
     s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
@@ -682,7 +716,11 @@ extern "C" void terra_scene_commit ( HTerraScene h ) {
         for ( size_t i = 0; i < s->objects_pop; ++i ) {
             const TerraAttribute& em = s->objects[i].material.emissive;
             TerraFloat3 e = em.value;
-            if ( em.state != nullptr ) continue;    // rejected in upload_scene with a message
+            if ( em.state != nullptr ) {            // reference src/Terra.c:199-200: evaluated at uv (0.5, 0.5)
+                if ( em.eval != terra_texture_sample ) continue;       // rejected in upload_scene with a message
+                TerraFloat2 uv = { 0.5f, 0.5f };
+                e = terra_texture_sample ( em.state, &uv, nullptr );
+            }
             if ( e.x == 0 && e.y == 0 && e.z == 0 ) continue;
             float area = 0;
             for ( size_t j = 0; j < s->objects[i].triangles_count; ++j ) area += triangle_area ( s->objects[i].triangles[j] );
@@ -694,7 +732,8 @@ extern "C" void terra_scene_commit ( HTerraScene h ) {
     s->dirty_objects = false; s->dirty_lights = false;
     s->committed = true;
     s->commit_error.clear();
-    if ( s->opts.environment_map.state != nullptr ) { fail ( kTerraAmdErrUnsupported, "textured environment map is not supported on the device yet" ); s->commit_error = g_last_error; s->device_ok = false; return; }
+    // The environment attribute only ever scales a throughput that is then discarded (reference src/Terra.c:1053-1058:
+    // the "Lo +=" is commented out), so neither a constant nor a textured environment reaches the image; nothing to upload.
     // options travel as kernel arguments; geometry/material/light changes need a new replica
     if ( ( rebuild || relight || !s->device_ok ) && upload_scene ( s ) != 0 ) { s->commit_error = g_last_error; s->device_ok = false; }
 }

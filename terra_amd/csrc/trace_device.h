@@ -408,6 +408,37 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
 }
 
 // -----------------------------------------------------------------------------
+// textures (reference src/Terra.c:368-466). uv is in TEXEL units, as the reference uses it
+// ((size_t)uv->x); three consecutive components are read whatever `components` says, as the
+// reference does; negative coordinates are undefined there and clamp to 0 here.
+// -----------------------------------------------------------------------------
+TD V3 texture_read ( const DevTexture& t, uint32_t x, uint32_t y ) {
+    const uint32_t W = t.width, H = t.height;
+    if ( t.address_mode == 2 ) { x = x < W - 1 ? x : W - 1; y = y < H - 1 ? y : H - 1; }
+    else if ( t.address_mode == 0 ) { x %= W; y %= H; }
+    else if ( ( x / W ) % 2 == 0 ) { x %= W; y %= H; }
+    else { x = W - ( x % W ); y = H - ( y % H ); x = x < W - 1 ? x : W - 1; y = y < H - 1 ? y : H - 1; }
+    const size_t e = ( ( size_t ) y * W + x ) * t.components;
+    if ( t.depth == 1 ) {
+        const uint8_t* p = reinterpret_cast<const uint8_t*> ( t.data ) + e;
+        return v3 ( p[0] / 255.f, p[1] / 255.f, p[2] / 255.f );
+    }
+    const float* p = reinterpret_cast<const float*> ( t.data ) + e;
+    return v3 ( p[0], p[1], p[2] );
+}
+TD V3 texture_sample ( const DevTexture& t, float u, float v ) {
+    uint32_t ix = u > 0.f ? ( uint32_t ) u : 0u, iy = v > 0.f ? ( uint32_t ) v : 0u;
+    if ( t.filter == 0 ) return texture_read ( t, ix, iy );
+    if ( t.filter != 1 ) return v3 ( 0, 0, 0 );          // trilinear / anisotropic: unimplemented in the reference too (returns zero)
+    uint32_t x2 = ix + 1 < t.width - 1 ? ix + 1 : t.width - 1, y2 = iy + 1 < t.height - 1 ? iy + 1 : t.height - 1;
+    V3 n1 = texture_read ( t, ix, iy ), n2 = texture_read ( t, x2, iy ), n3 = texture_read ( t, ix, y2 ), n4 = texture_read ( t, x2, y2 );
+    float wu = u - ( float ) ix, wv = v - ( float ) iy, wou = 1.f - wu, wov = 1.f - wv;
+    return v3 ( ( n1.x * wou + n2.x * wu ) * wov + ( n3.x * wou + n4.x * wu ) * wv,
+                ( n1.y * wou + n2.y * wu ) * wov + ( n3.y * wou + n4.y * wu ) * wv,
+                ( n1.z * wou + n2.z * wu ) * wov + ( n3.z * wou + n4.z * wu ) * wv );
+}
+
+// -----------------------------------------------------------------------------
 // surface
 // -----------------------------------------------------------------------------
 // The reference also stores the tangent frame (terra_f4x4_basis of the normal) in the
@@ -423,18 +454,18 @@ struct Surface {
 
 template <int MODE>
 TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint32_t& object_out, uint32_t& tri_in_object_out, uint32_t& nattr_out ) {
-    float4 t0, t1, t2, p0, p1, p2;
+    float4 t0, t1, t2, p0, p1, p2, p3x;
     if ( MODE == 1 ) {
         const float4* lt = reinterpret_cast<const float4*> ( T.l_tris );
         t0 = lt[3 * ti]; t1 = lt[3 * ti + 1]; t2 = lt[3 * ti + 2];
-        p0 = T.l_props[4 * ti]; p1 = T.l_props[4 * ti + 1]; p2 = T.l_props[4 * ti + 2];
+        p0 = T.l_props[4 * ti]; p1 = T.l_props[4 * ti + 1]; p2 = T.l_props[4 * ti + 2]; p3x = T.l_props[4 * ti + 3];
     } else {
         const float4* tris = reinterpret_cast<const float4*> ( MODE == 2 ? T.sc.fast_tris : T.sc.tris );
         const float4* props = reinterpret_cast<const float4*> ( T.sc.props );
         t0 = tris[3 * ti]; t1 = tris[3 * ti + 1]; t2 = tris[3 * ti + 2];
         uint32_t pi = ti;
         if ( MODE == 2 ) pi = T.sc.mats[__float_as_uint ( t0.w )].first_tri + __float_as_uint ( t1.w );
-        p0 = props[4 * pi]; p1 = props[4 * pi + 1]; p2 = props[4 * pi + 2];
+        p0 = props[4 * pi]; p1 = props[4 * pi + 1]; p2 = props[4 * pi + 2]; p3x = props[4 * pi + 3];
     }
     V3 ta = v3 ( t0.x, t0.y, t0.z ), tb = v3 ( t1.x, t1.y, t1.z ), tc = v3 ( t2.x, t2.y, t2.z );
     uint32_t object = __float_as_uint ( t0.w );
@@ -448,11 +479,20 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
     float w = 1 - u - v;
     V3 na = v3 ( p0.x, p0.y, p0.z ), nb = v3 ( p0.w, p1.x, p1.y ), nc = v3 ( p1.z, p1.w, p2.x );
     sf.normal = normalize ( ( nc * v + nb * u ) + na * w );
-    // texcoords are only consumed by textured attributes (not on the device yet): constants ignore them
     const DevMaterial& m = T.sc.mats[object];
     sf.emissive = v3p ( m.emissive );
     #pragma unroll
     for ( int i = 0; i < 4; ++i ) sf.attr[i] = v3p ( m.attributes[i] );
+    if ( m.any_texture ) {       // textured attributes: interpolate the texcoord as the reference does (src/Terra.c:1748-1752) and sample
+        V3 pa2 = v3 ( p2.y, p2.z, 0.f );            // texcoord_a
+        V3 pb2 = v3 ( p2.w, p3x.x, 0.f );           // texcoord_b
+        V3 pc2 = v3 ( p3x.y, p3x.z, 0.f );          // texcoord_c
+        float tx = ( pc2.x * v + pb2.x * u ) + pa2.x * w;
+        float ty = ( pc2.y * v + pb2.y * u ) + pa2.y * w;
+        #pragma unroll
+        for ( int i = 0; i < 4; ++i ) if ( m.tex[i] >= 0 ) sf.attr[i] = texture_sample ( T.sc.textures[m.tex[i]], tx, ty );
+        if ( m.tex[TERRA_DEV_MAX_ATTR] >= 0 ) sf.emissive = texture_sample ( T.sc.textures[m.tex[TERRA_DEV_MAX_ATTR]], tx, ty );
+    }
     sf.bsdf = m.bsdf;
     sf.ior = m.ior;
     nattr_out = m.attributes_count;

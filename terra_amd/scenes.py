@@ -24,11 +24,21 @@ FRAME_SEED = 0x5EED0001
 class Material:
     kind: str = "diffuse"                 # "diffuse" | "phong" | "ggx" | "glass" (the last two: this repo's own presets)
     roughness: float = 0.2
+    albedo_texture: Optional["TextureDesc"] = None       # replaces the constant albedo (slot 0 diffuse, slot 1 Phong)
+    emissive_texture: Optional["TextureDesc"] = None
     albedo: tuple = (0.73, 0.73, 0.73)
     emissive: tuple = (0.0, 0.0, 0.0)
     specular_color: tuple = (0.0, 0.0, 0.0)
     specular_intensity: float = 1.0
     ior: float = 1.5
+
+
+@dataclass
+class TextureDesc:
+    """A TerraTexture: data (h, w, c) uint8 or float32, c <= 3; lookups are in TEXEL units (reference src/Terra.c:410-414)."""
+    data: np.ndarray
+    filter: int = 0            # kTerraFilterPoint / 1 = bilinear
+    address_mode: int = 0      # wrap / 1 mirror / 2 clamp
 
 
 @dataclass
@@ -128,6 +138,40 @@ def cornell_box(width=256, height=256, spp=4, bounces=8, integrator=api.kTerraIn
     for k, v in kw.items():
         setattr(d, k, v)
     assert d.triangle_count == 32
+    return d
+
+
+def cornell_textured(width=256, height=256, spp=4, bounces=8, integrator=api.kTerraIntegratorSimple, mirror=False, **kw) -> SceneDesc:
+    """Cornell-32 with textured attributes: an 8x8 byte checker on the white object (point filter,
+    wrap), a 4x4 float texture on the red wall (bilinear, clamp), a Phong box with a bilinear byte texture as its albedo
+    (wrap; `mirror=True` switches it to the mirror mode, whose reference implementation reads one past the end
+    -- src/Terra.c:385-386 -- so that variant is only compared device vs oracle), and a textured emissive on the light. Texcoords are in texel units, as the reference samples them."""
+    d = cornell_box(width, height, spp, bounces, integrator)
+    r = np.random.RandomState(5)
+    def planar_uv(tris, ax0, ax1, scale, offset=0.0):
+        uv = np.zeros((len(tris), 3, 2), np.float32)
+        uv[..., 0] = (tris[..., ax0] + 1.0) * scale + offset
+        uv[..., 1] = (tris[..., ax1] + 1.0) * scale + offset
+        return uv
+    checker = np.zeros((8, 8, 3), np.uint8)
+    ii, jj = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    checker[(ii + jj) % 2 == 0] = (230, 225, 210); checker[(ii + jj) % 2 == 1] = (60, 90, 140)
+    white = d.objects[0]
+    uvw = planar_uv(white.triangles, 0, 2, 4.0)
+    uvw[4:6] = planar_uv(white.triangles[4:6], 0, 1, 4.0)          # back wall: x,y
+    d.objects[0] = ObjectDesc(white.triangles, white.normals, uvw, Material(albedo_texture=TextureDesc(checker, 0, 0)), "white_checker")
+    red = d.objects[1]
+    hdr = r.uniform(0.05, 0.9, size=(4, 4, 3)).astype(np.float32)
+    d.objects[1] = ObjectDesc(red.triangles, red.normals, planar_uv(red.triangles, 2, 1, 1.5, 0.25), Material(albedo_texture=TextureDesc(hdr, 1, 2)), "red_hdr_bilinear")
+    light = d.objects[3]
+    glow = np.array([[[15, 14, 12], [9, 12, 15]], [[15, 15, 15], [12, 9, 6]]], np.float32)
+    d.objects[3] = ObjectDesc(light.triangles, light.normals, planar_uv(light.triangles, 0, 2, 4.0, -2.9), Material(albedo=(0.78, 0.78, 0.78), emissive_texture=TextureDesc(glow, 0, 2)), "light_textured")
+    box = d.objects[4]
+    stripes = r.randint(30, 255, size=(4, 6, 3)).astype(np.uint8)
+    d.objects[4] = ObjectDesc(box.triangles, box.normals, planar_uv(box.triangles, 0, 1, 9.0), Material(kind="phong", specular_color=(0.4, 0.4, 0.4), specular_intensity=20.0, albedo_texture=TextureDesc(stripes, 1, 1 if mirror else 0)), "phong_tex")
+    d.name = "cornell32_textured"
+    for k, v in kw.items():
+        setattr(d, k, v)
     return d
 
 
@@ -328,6 +372,26 @@ def sponza_hall(width=1920, height=1080, spp=256, bounces=8, integrator=api.kTer
 # feeding a SceneDesc through the C API
 # --------------------------------------------------------------------------
 
+_keepalive = []      # TerraTexture structs must outlive the scenes that borrow them (reference src/Terra.c:294-304)
+
+
+def texture_attribute(lib: api.TerraLib, td: TextureDesc) -> api.TerraAttribute:
+    data = np.ascontiguousarray(td.data)
+    h, w, c = data.shape
+    tex = api.TerraTexture()
+    if data.dtype == np.uint8:
+        lib.texture_init(C.byref(tex), w, h, c, data.ctypes.data)
+    else:
+        data = data.astype(np.float32)
+        lib.texture_init_hdr(C.byref(tex), w, h, c, data.ctypes.data)
+    tex.filter = td.filter
+    tex.address_mode = td.address_mode
+    a = api.TerraAttribute()
+    lib.attribute_init_texture(C.byref(a), C.byref(tex))
+    _keepalive.append((tex, a))
+    return a
+
+
 def fill_object(lib: api.TerraLib, obj: api.TerraObject, od: ObjectDesc) -> None:
     n = len(od.triangles)
     tris = np.ascontiguousarray(od.triangles, dtype=np.float32).reshape(n, 9)
@@ -341,13 +405,14 @@ def fill_object(lib: api.TerraLib, obj: api.TerraObject, od: ObjectDesc) -> None
     mat.ior = m.ior
     mat.enable_bump_map_attr = False
     mat.enable_normal_map_attr = False
-    mat.emissive = api.const_attribute(lib, m.emissive)
+    mat.emissive = texture_attribute(lib, m.emissive_texture) if m.emissive_texture is not None else api.const_attribute(lib, m.emissive)
+    albedo_attr = texture_attribute(lib, m.albedo_texture) if m.albedo_texture is not None else api.const_attribute(lib, m.albedo)
     if m.kind == "diffuse":
-        mat.attributes[api.TERRA_DIFFUSE_ALBEDO] = api.const_attribute(lib, m.albedo)
+        mat.attributes[api.TERRA_DIFFUSE_ALBEDO] = albedo_attr
         mat.attributes_count = api.TERRA_DIFFUSE_END
         lib.bsdf_diffuse_init(C.byref(mat.bsdf))
     elif m.kind == "phong":
-        mat.attributes[api.TERRA_PHONG_ALBEDO] = api.const_attribute(lib, m.albedo)
+        mat.attributes[api.TERRA_PHONG_ALBEDO] = albedo_attr
         mat.attributes[api.TERRA_PHONG_SPECULAR_COLOR] = api.const_attribute(lib, m.specular_color)
         mat.attributes[api.TERRA_PHONG_SPECULAR_INTENSITY] = api.const_attribute(lib, (m.specular_intensity,) * 3)
         mat.attributes[api.TERRA_PHONG_SAMPLE_PICK] = api.const_attribute(lib, (0.0, 0.0, 0.0))

@@ -130,6 +130,13 @@ def main():
     L.scene_destroy(sc)
     manifest["files"]["render_hall"] = save("render_hall", **hall)
 
+    # textured attributes (byte/float textures, point/bilinear, wrap/clamp, textured emissive)
+    tex = {}
+    for integ in (0, 1, 2):
+        o6 = ref.render_pixels(scenes.cornell_textured(64, 48, 3, integrator=integ), passes=2)
+        tex[f"i{integ}_pixels"] = o6["pixels"]; tex[f"i{integ}_calls"] = o6["rand_calls"].astype(np.uint16)
+    manifest["files"]["render_textured"] = save("render_textured", **tex)
+
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1))
     total = sum(p.stat().st_size for p in HERE.glob("*.npz"))
     print(f"wrote {len(manifest['files'])} fixtures, {total / 1e6:.2f} MB")

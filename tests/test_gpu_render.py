@@ -355,3 +355,40 @@ def test_device_work_counters_equal_the_oracles(H, L, orc_lib, devmath_mode, nam
     for k in want:
         assert got[k] == want[k], (k, got[k], want[k])
     assert got["pixels"] == d.width * d.height and got["launches"] == 1
+
+
+# ---------------------------------------------------------------------------
+# textured attributes on the device
+# ---------------------------------------------------------------------------
+
+def test_textured_attributes_match_the_reference(H, L):
+    g = G(H, "render_textured")
+    for integ in (0, 1, 2):
+        d = scenes.cornell_textured(64, 48, 3, integrator=integ)
+        L.clear_error()
+        out = render_dev(L, d, passes=2, calls=True)
+        assert runtime.last_error() == "", runtime.last_error()
+        assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]), integ
+        assert np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32)), integ
+        assert H.same_bits(render_dev(L, d, passes=2, tree_mode=1)["pixels"], g[f"i{integ}_pixels"]), integ
+
+
+def test_mirror_addressing_and_texture_errors(H, L, orc_lib, devmath_mode):
+    d = scenes.cornell_textured(64, 48, 2, integrator=1, mirror=True)      # the reference's mirror mode reads out of bounds: device vs oracle only
+    assert H.same_bits(render_dev(L, d)["pixels"], H.Unit("orc").render_pixels(d, want_calls=False)["pixels"])
+    # a lat-long lookup bound to a material attribute is rejected (it reads past the texcoord in the reference)
+    import ctypes as C
+    d2 = scenes.cornell_box(16, 16, 1)
+    scene = L.scene_create()
+    for od in d2.objects:
+        scenes.fill_object(L, L.scene_add_object(scene, len(od.triangles)).contents, od)
+    tex = api.TerraTexture(); data = np.zeros((2, 2, 3), np.float32)
+    L.texture_init_hdr(C.byref(tex), 2, 2, 3, data.ctypes.data)
+    obj = L.scene_add_object(scene, 1).contents
+    scenes.fill_object(L, obj, scenes.ObjectDesc(d2.objects[0].triangles[:1], d2.objects[0].normals[:1], d2.objects[0].texcoords[:1]))
+    a = api.TerraAttribute(); L.attribute_init_cubemap(C.byref(a), C.byref(tex))
+    obj.material.attributes[0] = a
+    scenes.apply_options(L, scene, d2)
+    L.clear_error(); L.scene_commit(scene)
+    assert "terra_texture_sample" in runtime.last_error()
+    L.scene_destroy(scene)

@@ -150,3 +150,10 @@ def test_hall_generation_is_libm_free_and_stable(H):
     import hashlib
     h = hashlib.sha256(b"".join(o.triangles.tobytes() + o.normals.tobytes() for o in d.objects)).hexdigest()
     assert h == HALL_SHA256, h
+
+
+def test_textured_attributes(H, orc_lib):
+    g = G(H, "render_textured")
+    for integ in (0, 1, 2):
+        out = H.Unit("orc").render_pixels(scenes.cornell_textured(64, 48, 3, integrator=integ), passes=2)
+        assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]) and np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32))
