@@ -1150,7 +1150,7 @@ static void free_lights ( OrcScene* s ) {
 }
 void orc_scene_commit ( HTerraScene h ) {
     OrcScene* s = ( OrcScene* ) h;
-    bool dirty_acc = s->dirty_objects || s->opts.accelerator != s->new_opts.accelerator;
+    bool dirty_acc = s->dirty_objects || s->opts.accelerator != s->new_opts.accelerator || s->nodes == NULL;     /* a scene that never had an object has no tree in the reference (it would crash in traverse) */
     if ( dirty_acc ) bvh_destroy ( s );
     s->opts = s->new_opts;
     if ( dirty_acc ) bvh_build ( s );

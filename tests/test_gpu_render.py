@@ -392,3 +392,98 @@ def test_mirror_addressing_and_texture_errors(H, L, orc_lib, devmath_mode):
     L.clear_error(); L.scene_commit(scene)
     assert "terra_texture_sample" in runtime.last_error()
     L.scene_destroy(scene)
+
+
+# ---------------------------------------------------------------------------
+# empty, degenerate and ragged inputs
+# ---------------------------------------------------------------------------
+
+def _tri_scene(tris, w=24, h=16, spp=2, integ=0, emissive=(3.0, 2.0, 1.0)):
+    tris = np.asarray(tris, np.float32).reshape(-1, 3, 3)
+    nrm = np.zeros_like(tris); nrm[..., 2] = -1
+    objs = [scenes.ObjectDesc(tris, nrm, np.zeros((len(tris), 3, 2), np.float32), scenes.Material(albedo=(0.6, 0.5, 0.4), emissive=emissive))] if len(tris) else []
+    return scenes.SceneDesc(objects=objs, width=w, height=h, spp=spp, bounces=3, integrator=integ, camera_position=(0.0, 0.0, -3.0), name="tris")
+
+
+def test_empty_and_tiny_scenes(H, L, orc_lib, devmath_mode):
+    big = [[-1, -1, 1], [1, -1, 1], [0, 1, 1]]
+    cases = {
+        "no objects": _tri_scene([]),
+        "one triangle": _tri_scene([big]),
+        "two triangles": _tri_scene([big, [[-1, -1, 2], [1, -1, 2], [0, 1, 2]]]),
+        "degenerate triangle": _tri_scene([big, [[0, 0, 1], [0, 0, 1], [0, 0, 1]], [[-2, -2, 3], [2, -2, 3], [0, 2, 3]]]),
+        "coincident triangles (depth ties)": _tri_scene([big, big, big], integ=1),
+    }
+    for name, d in cases.items():
+        L.clear_error()
+        got = render_dev(L, d, calls=True)
+        assert runtime.last_error() == "", (name, runtime.last_error())
+        want = H.Unit("orc").render_pixels(d)
+        assert same(H, got["pixels"], want["pixels"]) and np.array_equal(got["rand_calls"], want["rand_calls"]), name
+        assert (got["samples"] == d.spp).all(), name
+    assert not render_dev(L, cases["no objects"])["pixels"].any()
+    # an object with zero triangles next to a normal one
+    d = _tri_scene([big])
+    d.objects.append(scenes.ObjectDesc(np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 2), np.float32)))
+    assert same(H, render_dev(L, d)["pixels"], H.Unit("orc").render_pixels(d, want_calls=False)["pixels"])
+
+
+def test_ragged_frames_and_tiles(H, L, orc_lib, devmath_mode):
+    for (w, h) in ((1, 1), (1, 37), (63, 1), (17, 9), (65, 65)):
+        d = scenes.cornell_box(w, h, 2, integrator=1)
+        want = H.Unit("orc").render_pixels(d, want_calls=False)
+        assert same(H, render_dev(L, d)["pixels"], want["pixels"]), (w, h)
+        assert same(H, render_host(L, d)["pixels"], want["pixels"]), (w, h)
+    d = scenes.cornell_box(70, 50, 2)
+    whole = render_dev(L, d)
+    rects = [(0, 0, 1, 1), (69, 49, 1, 1), (3, 5, 64, 1), (5, 0, 1, 50), (7, 9, 33, 17)]
+    for r in rects:
+        part = render_dev(L, d, rect=r)
+        x, y, w, h = r
+        assert H.same_bits(part["pixels"][y:y + h, x:x + w], whole["pixels"][y:y + h, x:x + w]), r
+        mask = np.ones((50, 70), bool); mask[y:y + h, x:x + w] = False
+        assert not part["pixels"][mask].any() and not part["samples"][mask].any(), r
+    # rectangles outside the frame are refused
+    import ctypes as C
+    scene = scenes.build_scene(L, d); cam = scenes.camera_of(d); fb = runtime.DeviceFramebuffer(70, 50)
+    assert L.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), 70, 50, 60, 0, 11, 5, None, None) < 0
+    assert L.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), 70, 50, 0, 0, 0, 5, None, None) < 0
+    L.scene_destroy(scene)
+
+
+def test_scene_lifecycle_recommit_clear_and_many_objects(H, L, orc_lib, devmath_mode):
+    import ctypes as C
+    d = scenes.cornell_box(40, 30, 2)
+    scene = scenes.build_scene(L, d); cam = scenes.camera_of(d)
+    fb = runtime.DeviceFramebuffer(40, 30)
+    runtime.render_device(L, cam, scene, fb)
+    # options are double buffered: editing them has no effect until the next commit (reference src/Terra.c:182,251-255)
+    L.scene_get_options(scene).contents.samples_per_pixel = 5
+    runtime.render_device(L, cam, scene, fb)
+    assert (fb.results_host()["samples"] == 4).all()
+    L.scene_commit(scene)
+    runtime.render_device(L, cam, scene, fb)
+    assert (fb.results_host()["samples"] == 9).all()
+    # clear + refill + commit builds a new replica
+    L.scene_clear(scene)
+    assert L.scene_count_objects(scene) == 0
+    d2 = scenes.cornell_phong(40, 30, 2, integrator=1)
+    for od in d2.objects:
+        scenes.fill_object(L, L.scene_add_object(scene, len(od.triangles)).contents, od)
+    scenes.apply_options(L, scene, d2)
+    L.clear_error(); L.scene_commit(scene)
+    assert runtime.last_error() == ""
+    fb.clear(); runtime.render_device(L, cam, scene, fb)
+    assert same(H, fb.pixels_host(), H.Unit("orc").render_pixels(d2, want_calls=False)["pixels"])
+    L.scene_destroy(scene)
+    # 256 objects is the limit of the 8-bit object index (reference include/Terra.h:195-198); 257 is refused
+    tri = d.objects[0]
+    for n, ok in ((256, True), (257, False)):
+        s2 = L.scene_create()
+        for k in range(n):
+            od = scenes.ObjectDesc(tri.triangles[:1] + np.float32(0.001 * k), tri.normals[:1], tri.texcoords[:1], scenes.Material(emissive=(1, 1, 1) if k == 0 else (0, 0, 0)))
+            scenes.fill_object(L, L.scene_add_object(s2, 1).contents, od)
+        scenes.apply_options(L, s2, d)
+        L.clear_error(); L.scene_commit(s2)
+        assert (runtime.last_error() == "") == ok, (n, runtime.last_error())
+        L.scene_destroy(s2)
