@@ -1,0 +1,113 @@
+"""apps/terra_headless.c: OBJ/MTL in, PNG/PPM/PFM/HDR out, Terra.h API only.
+The same C source is linked (a) against the compiled reference, here, where a deterministic debug
+integrator lets the loader/writers be checked exactly against a direct API render, and (b, gpu)
+against libterra_amd.so, where the full Direct render must equal the direct API render bit for bit."""
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from terra_amd import api, scenes
+
+
+def write_obj(d, path, mirror_z=False):
+    """exports a SceneDesc; mirror_z writes the right-handed twin (z negated, winding swapped) that the tool's default flip undoes"""
+    mtl = path.with_suffix(".mtl")
+    with open(path, "w") as f, open(mtl, "w") as m:
+        f.write(f"mtllib {mtl.name}\n")
+        vi = 1
+        for k, o in enumerate(d.objects):
+            mt = o.material
+            m.write(f"newmtl m{k}\nKd {mt.albedo[0]:.9g} {mt.albedo[1]:.9g} {mt.albedo[2]:.9g}\nKe {mt.emissive[0]:.9g} {mt.emissive[1]:.9g} {mt.emissive[2]:.9g}\n")
+            if mt.kind == "phong":
+                m.write(f"Ks {mt.specular_color[0]:.9g} {mt.specular_color[1]:.9g} {mt.specular_color[2]:.9g}\nNs {mt.specular_intensity:.9g}\n")
+            f.write(f"usemtl m{k}\n")
+            for t, n in zip(o.triangles, o.normals):
+                order = (0, 2, 1) if mirror_z else (0, 1, 2)
+                for c in order:
+                    z = -1.0 if mirror_z else 1.0
+                    f.write(f"v {t[c][0]:.9g} {t[c][1]:.9g} {t[c][2] * z:.9g}\nvn {n[c][0]:.9g} {n[c][1]:.9g} {n[c][2] * z:.9g}\n")
+                f.write(f"f {vi}//{vi} {vi + 1}//{vi + 1} {vi + 2}//{vi + 2}\n")
+                vi += 3
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0
+        return np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+
+
+def read_png(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    o, idat, w, h = 8, b"", 0, 0
+    while o < len(b):
+        n, typ = struct.unpack(">I4s", b[o:o + 8]); data = b[o + 8:o + 8 + n]
+        assert struct.unpack(">I", b[o + 8 + n:o + 12 + n])[0] == zlib.crc32(typ + data)
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", data[:10]); assert (depth, ctype) == (8, 2)
+        elif typ == b"IDAT":
+            idat += data
+        o += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert not raw[:, 0].any()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def build_tool(H, tmp_path, against):
+    exe = tmp_path / f"terra_headless_{against}"
+    if against == "ref":
+        cmd = ["gcc", "-std=gnu11", "-w", "-O1", "-I/root/reference/include", "-I/root/reference/src", str(H.ROOT / "apps/terra_headless.c"),
+               str(H.REF_SO), f"-Wl,-rpath,{H.REF_SO.parent}", "-lm", "-o", str(exe)]
+    else:
+        cmd = ["gcc", "-std=gnu11", "-Wall", "-O1", f"-I{H.ROOT / 'include'}", str(H.ROOT / "apps/terra_headless.c"), f"-L{H.ROOT / 'terra_amd'}", "-lterra_amd",
+               f"-Wl,-rpath,{H.ROOT / 'terra_amd'}", "-lm", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_tool_against_the_compiled_reference(H, ref_lib, tmp_path):
+    exe = build_tool(H, tmp_path, "ref")
+    d = scenes.cornell_phong(80, 60, 1, integrator=api.kTerraIntegratorDebugNormals, jitter=0.0, tonemap=api.kTerraTonemappingOperatorNone)
+    want = H.Unit("ref").render_pixels(d, want_calls=False)["pixels"]
+    for mirror, extra in ((False, ["--no-flip-z"]), (True, [])):
+        obj = tmp_path / f"cornell_{int(mirror)}.obj"
+        write_obj(d, obj, mirror_z=mirror)
+        out = tmp_path / f"n_{int(mirror)}.pfm"
+        r = subprocess.run([str(exe), str(obj), str(out), "--width", "80", "--height", "60", "--spp", "1", "--integrator", "normals", "--tonemap", "none"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "32 triangles, 6 materials" in r.stdout
+        assert np.array_equal(read_pfm(out), want), mirror
+    # the other writers carry the same pixels (PNG/PPM: clamp x 255)
+    for ext in ("png", "ppm", "hdr"):
+        out = tmp_path / f"img.{ext}"
+        r = subprocess.run([str(exe), str(obj), str(out), "--width", "80", "--height", "60", "--spp", "1", "--integrator", "normals", "--tonemap", "none"], capture_output=True, text=True)
+        assert r.returncode == 0 and out.stat().st_size > 1000
+    bytes_want = (np.clip(want, 0, 1) * np.float32(255)).astype(np.uint8)
+    assert np.array_equal(read_png(tmp_path / "img.png"), bytes_want)
+    ppm = open(tmp_path / "img.ppm", "rb").read()
+    assert ppm.startswith(b"P6\n80 60\n255\n") and np.array_equal(np.frombuffer(ppm[len(b"P6\n80 60\n255\n"):], np.uint8).reshape(60, 80, 3), bytes_want)
+
+
+@pytest.mark.gpu
+def test_tool_against_the_product(H, amd_lib, tmp_path):
+    from terra_amd import runtime
+    from test_gpu_render import render_host
+    L = runtime.load()
+    exe = build_tool(H, tmp_path, "amd")
+    d = scenes.cornell_phong(96, 64, 4, integrator=api.kTerraIntegratorDirect, jitter=0.5, tonemap=api.kTerraTonemappingOperatorReinhard, environment=(0.4, 0.52, 1.0))
+    want = render_host(L, d)["pixels"]
+    obj = tmp_path / "cornell.obj"
+    write_obj(d, obj, mirror_z=True)
+    out = tmp_path / "direct.pfm"
+    args = [str(exe), str(obj), str(out), "--width", "96", "--height", "64", "--spp", "4", "--bounces", "8", "--integrator", "direct", "--tonemap", "reinhard", "--jitter", "0.5", "--tile", "32"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert np.array_equal(read_pfm(out).view(np.uint32), want.view(np.uint32))
+    r = subprocess.run(args + ["--fast-tree"], capture_output=True, text=True)
+    assert r.returncode == 0 and np.array_equal(read_pfm(out).view(np.uint32), want.view(np.uint32))
