@@ -24,8 +24,10 @@ Also on the JSON line (rank 0):
                   duration measured with HIP events on the launch stream, against
                   the 8 TB/s HBM peak; traffic = measured HBM bytes per launch
                   from the committed rocprofv3 PMC passes (profiles/), or null.
-  cpu_baseline -- the oracle (CPU restatement, bit-exact to the reference) on all
-                  host cores over a bounded crop of the same workload (N=1 only).
+  cpu_baseline -- the reference's own CPU renderer (oracle/_ref, prebuilt from its unmodified
+                  sources; kind "reference") on all usable host cores over a bounded crop of the
+                  same workload, with the oracle's rate beside it (port_value); the oracle alone
+                  (kind "port") when the prebuilt reference library is absent. N=1 only.
 """
 from __future__ import annotations
 
@@ -91,19 +93,15 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 20.0):
-    """Oracle (port of the reference, libm math) on every host core over a centred crop at full spp."""
-    import subprocess
-    subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
-    orc = api.TerraLib(ROOT / "oracle" / "liboracle.so", "orc_")
-    cores = usable_cores()
-    f = orc.fn("orc_render_pixels_mt", None, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 4 + [C.c_uint64, C.c_void_p, C.c_int])
-    scene = scenes.build_scene(orc, d)
+def _time_cpu(lib, prefix, d, cores, seconds_budget):
+    """one CPU renderer (same C entry-point shape for the compiled reference and the oracle) over a centred crop at full spp"""
+    f = lib.fn(prefix + "render_pixels_mt", None, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 4 + [C.c_uint64, C.c_void_p, C.c_int])
+    scene = scenes.build_scene(lib, d)
     cam = scenes.camera_of(d)
-    fb = api.Framebuffer(orc, d.width, d.height)
+    fb = api.Framebuffer(lib, d.width, d.height)
     # calibrate on a thin strip, then size the crop for ~seconds_budget
     cw = min(d.width, 512); x0 = (d.width - cw) // 2; y0 = d.height // 2
-    rows0 = max(2, cores)
+    rows0 = max(4, cores)
     t = time.perf_counter(); f(C.byref(cam), scene, C.byref(fb.fb), x0, y0, cw, rows0, scenes.FRAME_SEED, None, cores); dt = time.perf_counter() - t
     rate = cw * rows0 * d.spp / max(dt, 1e-6)
     rows = int(max(8, min(d.height // 2, seconds_budget * rate / (cw * d.spp))))
@@ -111,9 +109,27 @@ def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 20.0):
     fb.clear()
     t = time.perf_counter(); f(C.byref(cam), scene, C.byref(fb.fb), x0, y1, cw, rows, scenes.FRAME_SEED, None, cores); dt = time.perf_counter() - t
     val = cw * rows * d.spp / dt / 1e6
-    fb.destroy(); orc.scene_destroy(scene)
-    return {"value": round(val, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{cw}x{rows} crop at x={x0},y={y1} of the {d.width}x{d.height} frame, full {d.spp} spp, {dt:.1f} s, oracle/liboracle.so on {cores} threads"}
+    fb.destroy(); lib.scene_destroy(scene)
+    return val, f"{cw}x{rows} crop at x={x0},y={y1} of the {d.width}x{d.height} frame, full {d.spp} spp, {dt:.1f} s"
+
+
+def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 12.0):
+    """The reference's own CPU renderer (oracle/_ref/libterra_ref.so: its unmodified sources compiled in the build
+    container with per-pixel pinned entropy; kind "reference") when that prebuilt library travelled with the tree, and the
+    oracle (bit-exact CPU restatement; kind "port") -- both on every usable host core, each over a bounded crop."""
+    import subprocess
+    cores = usable_cores()
+    subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    orc = api.TerraLib(ROOT / "oracle" / "liboracle.so", "orc_")
+    port, port_sample = _time_cpu(orc, "orc_", d, cores, seconds_budget)
+    ref_so = ROOT / "oracle" / "_ref" / "libterra_ref.so"
+    if ref_so.exists() and all(o.material.kind in ("diffuse", "phong") for o in d.objects):    # the reference has no GGX/glass preset
+        val, sample = _time_cpu(api.TerraLib(ref_so, "terra_"), "ref_", d, cores, seconds_budget)
+        return {"value": round(val, 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                "sample": sample + f", oracle/_ref/libterra_ref.so (the reference's sources, gcc -O2, one terra_render call per pixel) on {cores} threads",
+                "port_value": round(port, 3), "port_sample": port_sample + f", oracle/liboracle.so on {cores} threads"}
+    return {"value": round(port, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": port_sample + f", oracle/liboracle.so on {cores} threads"}
 
 
 def main():
