@@ -55,6 +55,16 @@ uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
 int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
 int  terra_amd_get_tree_mode ( HTerraScene scene );
 
+/* Environment lighting, off by default. The reference evaluates scene options' environment_map for a ray
+   that leaves the scene, multiplies the throughput by it and then drops the result: the line that would
+   add it is commented out (src/Terra.c:1053-1058), so the environment never reaches the image. With
+   on = 1 such a ray adds throughput * environment, where the attribute is a constant
+   (terra_attribute_init_constant) or a lat-long lookup by ray direction (terra_attribute_init_cubemap ->
+   terra_texture_sample_latlong, src/Terra.c:468-477). Takes effect at the next terra_scene_commit().
+   This changes images relative to the reference by design ("behind a flag"). */
+int  terra_amd_set_environment_lighting ( HTerraScene scene, int on );
+int  terra_amd_get_environment_lighting ( HTerraScene scene );
+
 /* Work counters of the device path, summed over all launches since the last
    reset. They define the algorithmic bytes of the roofline:
    bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels. */
@@ -159,7 +169,7 @@ int terra_amd_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3, c
 int terra_amd_unit_camera ( const TerraCamera* camera, size_t fb_width, size_t fb_height, int n, const uint32_t* xy2, float jitter, const float* r2, float* dirs3 );
 /* tonemap (src/Terra.c:578-627): colors3 in place */
 int terra_amd_unit_tonemap ( int op, float gamma, int n, float* colors3 );
-/* device math: fn 0 sinf, 1 cosf, 2 powf(x,y), 3 acosf */
+/* device math: fn 0 sinf, 1 cosf, 2 powf(x,y), 3 acosf, 4 atan2f(x,y) */
 int terra_amd_unit_math ( int fn, int n, const float* x, const float* y, float* out );
 
 #ifdef __cplusplus

@@ -68,6 +68,7 @@ float orc_math_sinf ( float x )  { return g_math_mode == ORC_MATH_LIBM ? sinf ( 
 float orc_math_cosf ( float x )  { return g_math_mode == ORC_MATH_LIBM ? cosf ( x ) : orc_dm_cosf ( x ); }
 float orc_math_powf ( float x, float y ) { return g_math_mode == ORC_MATH_LIBM ? powf ( x, y ) : orc_dm_powf ( x, y ); }
 float orc_math_acosf ( float x ) { return g_math_mode == ORC_MATH_LIBM ? acosf ( x ) : orc_dm_acosf ( x ); }
+float orc_math_atan2f ( float y, float x ) { return g_math_mode == ORC_MATH_LIBM ? atan2f ( y, x ) : orc_dm_atan2f ( y, x ); }
 
 /* ------------------------------------------------------------------------- */
 /* private types                                                              */
@@ -94,6 +95,7 @@ typedef struct {
     OrcBVHNode*  nodes;   int nodes_count; int max_stack;
     bool         dirty_objects, dirty_lights;
     uint64_t     frame_seed;
+    int          env_lighting;   /* extension, off by default: see orc_set_environment_lighting */
 } OrcScene;
 
 typedef struct { v3 origin, direction, inv_direction; } OrcRay;            /* reference src/TerraPrivate.h:107-111 */
@@ -210,9 +212,9 @@ TerraFloat3 orc_texture_sample ( void* tex, const void* uvp, const void* xyz ) {
 TerraFloat3 orc_texture_sample_latlong ( void* tex, const void* dirp, const void* xyz ) { /* reference src/Terra.c:468-477 */
     TerraTexture* t = ( TerraTexture* ) tex; ( void ) xyz;
     v3 d = v3_norm ( * ( const v3* ) dirp );
-    float theta = acosf ( d.y );
-    float phi = atan2f ( d.z, d.x ) + terra_PI;
-    size_t u = ( size_t ) ( ( phi / ( 2 * terra_PI ) ) * t->width );
+    float theta = orc_math_acosf ( d.y );
+    float phi = orc_math_atan2f ( d.z, d.x ) + terra_PI;
+    size_t u = ( size_t ) ( ( phi / ( 2 * terra_PI ) ) * t->width );      /* < width: terra_PI exceeds pi, so phi / (2 terra_PI) < 1 */
     size_t v = ( size_t ) ( ( theta / ( terra_PI ) ) * t->height );
     return orc_texture_read ( t, u, v );
 }
@@ -982,7 +984,14 @@ static v3 trace ( const OrcScene* s, const OrcRay* primary ) {
     for ( size_t bounce = 0; bounce <= s->opts.bounces; ++bounce ) {
         TerraShadingSurface sf; v3 p;
         int oi = scene_raycast ( s, &ray, &sf, &p, NULL );
-        if ( oi < 0 ) break;         /* environment only scales a throughput that is then discarded (:1053-1058) */
+        if ( oi < 0 ) {              /* the reference scales the throughput by the environment and then discards it (:1053-1058) */
+            if ( s->env_lighting ) { /* extension: what the commented-out "Lo += throughput" (:1056) would add */
+                v3 env = attribute_eval ( &s->opts.environment_map, &ray.direction, &p );
+                throughput = v3_mul ( throughput, env );
+                Lo = v3_add ( Lo, throughput );
+            }
+            break;
+        }
         const TerraObject* obj = &s->objects[oi];
         v3 wo = v3_neg ( ray.direction );
         Lo = v3_add ( Lo, integrate ( s, &ray, obj, &sf, p, wo, throughput, bounce ) );
@@ -1116,6 +1125,7 @@ void orc_render ( const TerraCamera* cam, HTerraScene h, const TerraFramebuffer*
     orc_render_pixels ( cam, h, fb, x, y, w, hgt, ( ( OrcScene* ) h )->frame_seed, NULL );
 }
 void orc_set_frame_seed ( HTerraScene h, uint64_t seed ) { ( ( OrcScene* ) h )->frame_seed = seed; }
+void orc_set_environment_lighting ( HTerraScene h, int on ) { ( ( OrcScene* ) h )->env_lighting = on != 0; }
 
 /* ------------------------------------------------------------------------- */
 /* scene lifecycle (reference src/Terra.c:130-282)                             */
@@ -1212,8 +1222,9 @@ void orc_devmath_sincos_domain_check ( uint64_t* sin_mismatch, uint64_t* cos_mis
 /* fn: 0 sinf 1 cosf 2 powf 3 acosf; mode: ORC_MATH_LIBM / ORC_MATH_DEVMATH */
 void orc_math_eval ( int fn, int mode, int n, const float* x, const float* y, float* out ) {
     for ( int i = 0; i < n; ++i ) {
-        if ( mode == ORC_MATH_LIBM ) out[i] = fn == 0 ? sinf ( x[i] ) : fn == 1 ? cosf ( x[i] ) : fn == 2 ? powf ( x[i], y[i] ) : acosf ( x[i] );
-        else out[i] = fn == 0 ? orc_dm_sinf ( x[i] ) : fn == 1 ? orc_dm_cosf ( x[i] ) : fn == 2 ? orc_dm_powf ( x[i], y[i] ) : orc_dm_acosf ( x[i] );
+        /* fn: 0 sinf, 1 cosf, 2 powf(x,y), 3 acosf, 4 atan2f(x,y) */
+        if ( mode == ORC_MATH_LIBM ) out[i] = fn == 0 ? sinf ( x[i] ) : fn == 1 ? cosf ( x[i] ) : fn == 2 ? powf ( x[i], y[i] ) : fn == 3 ? acosf ( x[i] ) : atan2f ( x[i], y[i] );
+        else out[i] = fn == 0 ? orc_dm_sinf ( x[i] ) : fn == 1 ? orc_dm_cosf ( x[i] ) : fn == 2 ? orc_dm_powf ( x[i], y[i] ) : fn == 3 ? orc_dm_acosf ( x[i] ) : orc_dm_atan2f ( x[i], y[i] );
     }
 }
 

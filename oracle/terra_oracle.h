@@ -66,6 +66,9 @@ enum { ORC_MATH_LIBM = 0, ORC_MATH_DEVMATH = 1 };
 void     orc_set_math_mode ( int mode );
 int      orc_get_math_mode ( void );
 void     orc_set_frame_seed ( HTerraScene scene, uint64_t seed );
+/* extension mirrored from terra_amd_set_environment_lighting(): a ray that leaves the scene adds
+   throughput * environment (the line the reference has commented out, src/Terra.c:1056). Off by default. */
+void     orc_set_environment_lighting ( HTerraScene scene, int on );
 
 /* work counters accumulated by every raycast since the last reset (thread-safe sums) */
 typedef struct {

@@ -102,7 +102,16 @@ struct DevScene {
     const DevTri*      fast_tris;
     uint32_t n_fast_nodes;
     int32_t  fast_max_stack;
+    // environment lighting (terra_amd_set_environment_lighting; off = the reference's behaviour):
+    // 0 off, 1 constant env_color, 2 lat-long lookup of textures[env_tex] by ray direction
+    int32_t  env_mode;
+    int32_t  env_tex;
+    float    env_color[3];
 };
+// bit of the kernels' KINDS mask (bits 0-3 = DevBsdfKind present) that compiles the environment term in
+#define TERRA_KIND_ENV 16
+// ... and the bit that compiles textured-attribute sampling into terra_surface_init's counterpart
+#define TERRA_KIND_TEX 32
 
 // indices into the device counter array (uint64 each); mirrors TerraAmdStats
 enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrCount };

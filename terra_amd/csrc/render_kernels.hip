@@ -79,9 +79,12 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
 #ifndef TERRA_WAVES_LIGHT
 #define TERRA_WAVES_LIGHT 4
 #endif
-#define TERRA_WAVES_FOR(I) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : TERRA_WAVES_SIMPLE )
+#ifndef TERRA_WAVES_GENERIC      // Simple/debug kernels compiled for every preset, textures and the environment term (KINDS != diffuse-only)
+#define TERRA_WAVES_GENERIC TERRA_WAVES_SIMPLE
+#endif
+#define TERRA_WAVES_FOR(I, K) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
-__global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_render_kernel ( DevRenderParams p ) {
+__global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
     const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
@@ -121,7 +124,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_
             Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++s;
         }
         Surface sf;
-        RaycastResult h = scene_raycast<COUNT, MODE> ( T, ray, sf, c );
+        RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
         bool end = !h.hit;
         if ( h.hit ) {
             V3 wo = neg ( ray.d );
@@ -142,6 +145,9 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR ) ) void terra_
                 ++bounce;
                 end = bounce > p.bounces;
             }
+        } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
+            throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
+            Lo = Lo + throughput;
         }
         if ( end ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; alive = false; }
     }

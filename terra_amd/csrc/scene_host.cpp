@@ -238,6 +238,7 @@ struct Scene {
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
     int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree (terra_amd_set_tree_mode)
+    bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
 };
@@ -275,6 +276,12 @@ extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
     return 0;
 }
 extern "C" int terra_amd_get_tree_mode ( HTerraScene h ) { return S ( h )->tree_mode; }
+extern "C" int terra_amd_set_environment_lighting ( HTerraScene h, int on ) {
+    Scene* s = S ( h );
+    if ( s->env_lighting != ( on != 0 ) ) { s->env_lighting = on != 0; s->dirty_lights = true; s->committed = false; }
+    return 0;
+}
+extern "C" int terra_amd_get_environment_lighting ( HTerraScene h ) { return S ( h )->env_lighting ? 1 : 0; }
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
 extern "C" uint64_t terra_amd_get_frame_seed ( HTerraScene h ) { return S ( h )->frame_seed; }
 
@@ -577,7 +584,24 @@ static int upload_scene ( Scene* s ) {
     s->uniform_attr_count = nobj ? ( int ) mats[0].attributes_count : -1;
     for ( size_t j = 1; j < nobj; ++j ) if ( ( int ) mats[j].attributes_count != s->uniform_attr_count ) s->uniform_attr_count = -1;
     s->bsdf_kinds = 0;
-    for ( size_t j = 0; j < nobj; ++j ) s->bsdf_kinds |= 1u << mats[j].bsdf;
+    for ( size_t j = 0; j < nobj; ++j ) { s->bsdf_kinds |= 1u << mats[j].bsdf; if ( mats[j].any_texture ) s->bsdf_kinds |= TERRA_KIND_TEX; }
+    // environment (extension, off by default): constant colour or a lat-long lookup (reference src/Terra.c:468-477)
+    int32_t env_mode = 0, env_tex = -1; float env_color[3] = { 0.f, 0.f, 0.f };
+    if ( s->env_lighting ) {
+        const TerraAttribute& env = s->opts.environment_map;
+        if ( env.state == nullptr ) {
+            env_mode = 1; env_color[0] = env.value.x; env_color[1] = env.value.y; env_color[2] = env.value.z;
+        } else {
+            if ( env.eval != terra_texture_sample_latlong ) return fail ( kTerraAmdErrUnsupported, "environment: with environment lighting on, the attribute must be a constant or terra_attribute_init_cubemap (a lat-long lookup by direction)" );
+            const TerraTexture* t = ( const TerraTexture* ) env.state;
+            if ( !t->pixels || !t->width || !t->height || ( t->depth != 1 && t->depth != 4 ) || t->components == 0 ) return fail ( kTerraAmdErrBadArgument, "environment: invalid texture" );
+            size_t k = 0;
+            for ( ; k < textures.size(); ++k ) if ( textures[k] == t ) break;
+            if ( k == textures.size() ) textures.push_back ( t );
+            env_mode = 2; env_tex = ( int32_t ) k;
+        }
+        s->bsdf_kinds |= TERRA_KIND_ENV;
+    }
     // flatten
     std::vector<DevTri> tris ( ntri ? ntri : 1 );
     std::vector<DevProps> props ( ntri ? ntri : 1 );
@@ -700,6 +724,7 @@ static int upload_scene ( Scene* s ) {
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
     s->dev.fast_nodes = fnodes.empty() ? nullptr : ( const DevNode* ) ( base + o_fn ); s->dev.fast_tris = fnodes.empty() ? nullptr : ( const DevTri* ) ( base + o_ft );
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
+    s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
     s->device_ok = true;
     return 0;
 }
@@ -707,6 +732,7 @@ static int upload_scene ( Scene* s ) {
 extern "C" void terra_scene_commit ( HTerraScene h ) {
     Scene* s = S ( h );
     const bool rebuild = s->dirty_objects || s->opts.accelerator != s->new_opts.accelerator || s->nodes.empty();
+    const bool env_changed = s->env_lighting && memcmp ( &s->opts.environment_map, &s->new_opts.environment_map, sizeof ( TerraAttribute ) ) != 0;
     s->opts = s->new_opts;
     if ( rebuild ) bvh::build ( s->objects, s->objects_pop, s->nodes, s->max_stack );
     const bool relight = s->dirty_lights || rebuild;
@@ -733,9 +759,10 @@ extern "C" void terra_scene_commit ( HTerraScene h ) {
     s->committed = true;
     s->commit_error.clear();
     // The environment attribute only ever scales a throughput that is then discarded (reference src/Terra.c:1053-1058:
-    // the "Lo +=" is commented out), so neither a constant nor a textured environment reaches the image; nothing to upload.
+    // the "Lo +=" is commented out), so by default neither a constant nor a textured environment reaches the image and
+    // nothing is uploaded for it; terra_amd_set_environment_lighting(scene, 1) turns that line on (upload_scene binds it).
     // options travel as kernel arguments; geometry/material/light changes need a new replica
-    if ( ( rebuild || relight || !s->device_ok ) && upload_scene ( s ) != 0 ) { s->commit_error = g_last_error; s->device_ok = false; }
+    if ( ( rebuild || relight || env_changed || !s->device_ok ) && upload_scene ( s ) != 0 ) { s->commit_error = g_last_error; s->device_ok = false; }
 }
 
 extern "C" int terra_amd_scene_info ( HTerraScene h, TerraAmdSceneInfo* out ) {

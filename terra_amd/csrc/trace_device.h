@@ -438,6 +438,20 @@ TD V3 texture_sample ( const DevTexture& t, float u, float v ) {
                 ( n1.z * wou + n2.z * wu ) * wov + ( n3.z * wou + n4.z * wu ) * wv );
 }
 
+#define TERRA_PI_F 3.1416926535f        // the reference's terra_PI (include/TerraMath.h), not pi
+// lat-long environment lookup by direction (reference src/Terra.c:468-477): nearest texel, no filtering.
+// terra_PI exceeds pi, so phi / (2 terra_PI) and theta / terra_PI stay below 1 and the texel is in range.
+TD V3 environment_eval ( const DevScene& sc, V3 dir ) {
+    if ( sc.env_mode == 1 ) return v3 ( sc.env_color[0], sc.env_color[1], sc.env_color[2] );
+    const DevTexture& t = sc.textures[sc.env_tex];
+    V3 d = normalize ( dir );
+    float theta = tdm_acosf ( d.y );
+    float phi = tdm_atan2f ( d.z, d.x ) + TERRA_PI_F;
+    uint32_t u = ( uint32_t ) ( ( phi / ( 2 * TERRA_PI_F ) ) * ( float ) t.width );
+    uint32_t v = ( uint32_t ) ( ( theta / TERRA_PI_F ) * ( float ) t.height );
+    return texture_read ( t, u, v );
+}
+
 // -----------------------------------------------------------------------------
 // surface
 // -----------------------------------------------------------------------------
@@ -452,7 +466,7 @@ struct Surface {
     int   bsdf;
 };
 
-template <int MODE>
+template <int MODE, int KINDS>
 TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint32_t& object_out, uint32_t& tri_in_object_out, uint32_t& nattr_out ) {
     float4 t0, t1, t2, p0, p1, p2, p3x;
     if ( MODE == 1 ) {
@@ -483,7 +497,7 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
     sf.emissive = v3p ( m.emissive );
     #pragma unroll
     for ( int i = 0; i < 4; ++i ) sf.attr[i] = v3p ( m.attributes[i] );
-    if ( m.any_texture ) {       // textured attributes: interpolate the texcoord as the reference does (src/Terra.c:1748-1752) and sample
+    if ( ( KINDS & TERRA_KIND_TEX ) && m.any_texture ) {       // textured attributes: interpolate the texcoord as the reference does (src/Terra.c:1748-1752) and sample
         V3 pa2 = v3 ( p2.y, p2.z, 0.f );            // texcoord_a
         V3 pb2 = v3 ( p2.w, p3x.x, 0.f );           // texcoord_b
         V3 pc2 = v3 ( p3x.y, p3x.z, 0.f );          // texcoord_c
@@ -500,7 +514,7 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
 
 struct RaycastResult { bool hit; uint32_t object, tri_in_object, tri; V3 point; };
 
-template <int COUNT, int MODE>
+template <int COUNT, int MODE, int KINDS>
 TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Counters& c ) {
     Ray r = in;
     r.o = r.o + r.d * 0.001f;
@@ -513,7 +527,7 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
     res.point = res.hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
     if ( res.hit ) {
         uint32_t nattr;
-        surface_init<MODE> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
+        surface_init<MODE, KINDS> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
         if ( MODE == 2 ) res.tri = T.sc.mats[res.object].first_tri + res.tri_in_object;      // back to the soup index (lights, areas)
         if ( COUNT ) ++c.hits;
         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
@@ -529,7 +543,6 @@ TD Ray surface_ray ( const Surface& sf, V3 p, V3 d, float sign ) {
 // -----------------------------------------------------------------------------
 // BSDF presets
 // -----------------------------------------------------------------------------
-#define TERRA_PI_F 3.1416926535f
 
 TD V3 diffuse_sample ( const Surface& sf, float e1, float e2 ) {
     float r = sqrtf ( e1 );
@@ -668,7 +681,7 @@ TD V3 glass_eval ( const Surface& sf, V3 wi ) {
 // BSDF dispatch. KINDS is a compile-time mask of the preset kinds present in the committed scene
 // (bit k = DevBsdfKind k): a diffuse-only scene compiles to straight-line diffuse code, which is
 // what keeps the Simple kernel inside 96 VGPRs (5 waves/SIMD) without scratch.
-#define TERRA_KINDS_ALL 15
+#define TERRA_KINDS_ALL 63
 template <int KINDS>
 TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
     if ( ( KINDS & 2 ) && ( KINDS == 2 || sf.bsdf == kDevBsdfPhong ) ) return phong_sample ( sf, e1, e2, e3, wo );
@@ -738,7 +751,7 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
     V3 wi = normalize ( p_to_light );
     Surface lsf;
     Ray r = surface_ray ( sf, p, wi, 1.f );
-    RaycastResult h = scene_raycast<COUNT, MODE> ( T, r, lsf, c );
+    RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, r, lsf, c );
     if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
         float cosv = dot ( neg ( wi ), ls.norm );
         if ( cosv > 0 ) {
@@ -766,7 +779,7 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
         V3 wi = normalize ( p_to_light );
         Surface lsf;
         Ray r = surface_ray ( sf, p, wi, 1.f );
-        RaycastResult h = scene_raycast<COUNT, MODE> ( T, r, lsf, c );
+        RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, r, lsf, c );
         if ( h.hit && h.object == ls.light_object && h.tri_in_object == ls.tri_in_object ) {
             float cosv = dot ( ls.norm, neg ( wi ) );
             if ( cosv > 0 ) {
@@ -794,7 +807,7 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
         V3 light_wo = neg ( wi );
         Surface lsf;
         Ray r = surface_ray ( sf, p, wi, 1.f );
-        RaycastResult h = scene_raycast<COUNT, MODE> ( T, r, lsf, c );
+        RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, r, lsf, c );
         if ( h.hit && h.object == ls.light_object ) {
             float NoW = dot ( lsf.normal, light_wo );
             if ( NoW > 0 ) {
@@ -866,8 +879,11 @@ TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counte
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     for ( uint32_t bounce = 0; bounce <= bounces; ++bounce ) {
         Surface sf;
-        RaycastResult h = scene_raycast<COUNT, MODE> ( T, ray, sf, c );
-        if ( !h.hit ) break;
+        RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
+        if ( !h.hit ) {
+            if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
+            break;
+        }
         V3 wo = neg ( ray.d );
         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rb, c );
         float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );

@@ -120,7 +120,7 @@ __global__ __launch_bounds__ ( 256 ) void k_raycast ( DevScene sc, int n, const 
     Counters c = counters_zero();
     Surface sf;
     Tracer T = unit_tracer ( sc, lds_stack );
-    RaycastResult h = scene_raycast<0, 0> ( T, r, sf, c );
+    RaycastResult h = scene_raycast<0, 0, TERRA_KINDS_ALL> ( T, r, sf, c );
     obj[i] = h.hit ? ( int ) h.object : -1;
     tri[i] = h.hit ? ( int ) h.tri_in_object : 0;
     point[3 * i] = h.point.x; point[3 * i + 1] = h.point.y; point[3 * i + 2] = h.point.z;
@@ -210,7 +210,8 @@ __global__ void k_math ( int fn, int n, const float* x, const float* y, float* o
         case 0: r = tdm_sinf ( x[i] ); break;
         case 1: r = tdm_cosf ( x[i] ); break;
         case 2: r = tdm_powf ( x[i], y[i] ); break;
-        default: r = tdm_acosf ( x[i] ); break;
+        case 3: r = tdm_acosf ( x[i] ); break;
+        default: r = tdm_atan2f ( x[i], y[i] ); break;
     }
     out[i] = r;
 }

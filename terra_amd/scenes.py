@@ -69,6 +69,8 @@ class SceneDesc:
     exposure: float = 1.0
     gamma: float = 2.2
     environment: tuple = (0.0, 0.0, 0.0)
+    environment_texture: Optional["TextureDesc"] = None   # lat-long map bound with terra_attribute_init_cubemap
+    environment_lighting: bool = False     # extension (terra_amd_/orc_set_environment_lighting); the reference drops the environment term
     name: str = "scene"
 
     @property
@@ -375,7 +377,7 @@ def sponza_hall(width=1920, height=1080, spp=256, bounces=8, integrator=api.kTer
 _keepalive = []      # TerraTexture structs must outlive the scenes that borrow them (reference src/Terra.c:294-304)
 
 
-def texture_attribute(lib: api.TerraLib, td: TextureDesc) -> api.TerraAttribute:
+def texture_attribute(lib: api.TerraLib, td: TextureDesc, latlong: bool = False) -> api.TerraAttribute:
     data = np.ascontiguousarray(td.data)
     h, w, c = data.shape
     tex = api.TerraTexture()
@@ -387,7 +389,7 @@ def texture_attribute(lib: api.TerraLib, td: TextureDesc) -> api.TerraAttribute:
     tex.filter = td.filter
     tex.address_mode = td.address_mode
     a = api.TerraAttribute()
-    lib.attribute_init_texture(C.byref(a), C.byref(tex))
+    (lib.attribute_init_cubemap if latlong else lib.attribute_init_texture)(C.byref(a), C.byref(tex))
     _keepalive.append((tex, a))
     return a
 
@@ -435,7 +437,7 @@ def fill_object(lib: api.TerraLib, obj: api.TerraObject, od: ObjectDesc) -> None
 
 def apply_options(lib: api.TerraLib, scene, d: SceneDesc) -> None:
     o = lib.scene_get_options(scene).contents
-    o.environment_map = api.const_attribute(lib, d.environment)
+    o.environment_map = texture_attribute(lib, d.environment_texture, latlong=True) if d.environment_texture is not None else api.const_attribute(lib, d.environment)
     o.tonemapping_operator = d.tonemap
     o.accelerator = api.kTerraAcceleratorBVH
     o.sampling_method = d.sampling
@@ -455,6 +457,11 @@ def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode: int = 0):
     if tree_mode:
         f = lib.fn("terra_amd_set_tree_mode", C.c_int, [C.c_void_p, C.c_int])
         assert f(scene, tree_mode) == 0
+    if d.environment_lighting:      # the reference has no such switch: its environment term never reaches the image
+        sym = {"terra_": "terra_amd_set_environment_lighting", "orc_": "orc_set_environment_lighting"}[lib.prefix]
+        if not lib.has(sym):
+            raise ValueError("environment lighting is an extension of libterra_amd.so / the oracle; this library has no such switch")
+        lib.fn(sym, C.c_int if lib.prefix == "terra_" else None, [C.c_void_p, C.c_int])(scene, 1)
     for od in d.objects:
         obj = lib.scene_add_object(scene, len(od.triangles)).contents
         fill_object(lib, obj, od)

@@ -155,6 +155,8 @@ def test_device_math_vs_oracle_and_libm(H, L, orc_lib):
         2: (np.concatenate([r.uniform(0, 1, n // 2), r.uniform(-1, 1, n // 4), r.uniform(0, 30, n // 4)]).astype(np.float32),
             np.concatenate([1 / (1 + np.round(r.uniform(0, 80, n // 2))), np.round(r.uniform(0, 60, n // 4)), np.full(n // 4, 1 / 2.2)]).astype(np.float32)),
         3: (r.uniform(-1.01, 1.01, n).astype(np.float32), None),
+        4: (np.concatenate([r.uniform(-1, 1, n - 8), [0, -0.0, 0, 1, -1, 1e-30, 3e30, -2]]).astype(np.float32),
+            np.concatenate([r.uniform(-1, 1, n - 8), [1, -1, 0, 0, 0, -3e30, 1e-30, 1]]).astype(np.float32)),
     }
     for fn, (x, y) in cases.items():
         x = np.ascontiguousarray(x, np.float32); yy = np.ascontiguousarray(y if y is not None else x, np.float32)

@@ -2,8 +2,8 @@
 
 sinf/cosf must equal glibc on EVERY argument the diffuse sampler can produce, so
 that diffuse-only scenes are bit-identical to the reference end to end.
-powf/acosf restate the published algorithms glibc 2.35 uses (table+polynomial powf,
-fdlibm float acosf) and must agree with this host's libm on every sampled argument
+powf/acosf/atan2f restate the published algorithms glibc 2.35 uses (table+polynomial powf,
+fdlibm float acosf, atanf and atan2f) and must agree with this host's libm on every sampled argument
 (NaN results: NaN-ness only, payload/sign unspecified)."""
 import ctypes as C
 
@@ -73,3 +73,16 @@ def test_acosf_close_to_libm(H, orc_lib):
     rate = (d != 0).mean()
     print(f"acosf: mismatch rate {rate:.2e}, max ulp {d.max()}")
     assert d.max() == 0 and rate == 0
+
+
+def test_atan2f_equals_libm(H, orc_lib):
+    """the lat-long environment lookup (reference src/Terra.c:468-477) is the only atan2f user"""
+    r = H.rng(8)
+    n = 500000
+    raw = r.randint(0, 2 ** 32, (2, n), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    y = np.concatenate([r.uniform(-1, 1, n), raw[0], [0, -0.0, 0, -0.0, 1, -1, np.inf, -np.inf, np.inf, 1, 1e-30]]).astype(np.float32)
+    x = np.concatenate([r.uniform(-1, 1, n), raw[1], [1, 1, -1, -1, 0, 0, np.inf, -np.inf, 1, -np.inf, -3e30]]).astype(np.float32)
+    a, b = _eval(orc_lib, 4, 0, y, x), _eval(orc_lib, 4, 1, y, x)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    ok = ~np.isnan(a)
+    assert np.array_equal(H_bits(a[ok]), H_bits(b[ok]))
