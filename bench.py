@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
     ap.add_argument("--tree", default="reference", choices=["reference", "fast"], help="reference = the reference's own tree and traversal order (parity mode, the headline); fast = terra_amd_set_tree_mode(1)")
+    ap.add_argument("--sample-split", type=int, default=8, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
     ap.add_argument("--check", action="store_true", help="after timing: one sharded+gathered pass on a cleared frame must equal an unsharded pass bit for bit (rank 0)")
     args = ap.parse_args()
 
@@ -175,6 +176,7 @@ def main():
     scene = scenes.build_scene(lib, d, tree_mode=1 if args.tree == "fast" else 0)
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
+    runtime.check(lib.set_sample_split(scene, args.sample_split), "terra_amd_set_sample_split")
     cam = scenes.camera_of(d)
     fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
     n_packed = runtime.packed_floats_per_rank(d.width, d.height, TILE, world)
@@ -245,14 +247,16 @@ def main():
         traffic = None
         tf = ROOT / "profiles" / "roofline_traffic.json"
         if tf.exists() and world == 1 and not args.spp:
-            traffic = json.loads(tf.read_text()).get(args.workload, {}).get("hbm_bytes_per_launch")
+            rec = json.loads(tf.read_text()).get(args.workload, {})
+            if rec.get("sample_split", 1) == args.sample_split and args.tree == "reference":      # the PMC passes were taken on this configuration
+                traffic = rec.get("hbm_bytes_per_launch")
         out = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces,
                        "integrator": "simple" if d.integrator == 0 else ("direct" if d.integrator == 1 else str(d.integrator)),
-                       "triangles": d.triangle_count, "tree": args.tree, "tile": TILE, "parallelism": f"tiles%{world}" if world > 1 else "single"},
+                       "triangles": d.triangle_count, "tree": args.tree, "tile": TILE, "sample_split": args.sample_split, "parallelism": f"tiles%{world}" if world > 1 else "single"},
             "mrays_per_s": round(st["rays"] / max(1, st["launches"]) * (1 if world == 1 else world) / (kernel_ms * 1e-3) / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3),

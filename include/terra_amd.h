@@ -55,6 +55,17 @@ uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
 int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
 int  terra_amd_get_tree_mode ( HTerraScene scene );
 
+/* Sample split: how many lanes share one pixel. With split = S (1, 2, 4, 8 or 16; default 1) a render call of
+   spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random
+   streams keyed (pixel, samples already in the pixel + j * spp/S), and the chunk sums are added to the
+   pixel in chunk order: bit for bit the framebuffer that S successive calls of spp/S samples produce
+   (each call of the reference sums its own samples and then adds them to the running sum,
+   src/Terra.c:551-572). It exists for small tiles and shards: one GPU has more lanes than a 1/8 share
+   of a 1080p frame has pixels. If spp is not a multiple of S the largest power of two dividing it is
+   used. A launch parameter: no commit needed. */
+int  terra_amd_set_sample_split ( HTerraScene scene, int split );
+int  terra_amd_get_sample_split ( HTerraScene scene );
+
 /* Environment lighting, off by default. The reference evaluates scene options' environment_map for a ray
    that leaves the scene, multiplies the throughput by it and then drops the result: the line that would
    add it is commented out (src/Terra.c:1053-1058), so the environment never reaches the image. With

@@ -130,6 +130,13 @@ struct DevRenderParams {
     uint32_t x, y, w, h;            // rectangle to render
     uint32_t tile_size, rank, world; // sharding: tiles t with t % world == rank (world == 1: everything)
     uint32_t spp;                   // effective samples per pixel (after the stratified round-up)
+    // sample split (terra_amd_set_sample_split): the call's spp samples are cut into `split` = 2^split_log2 chunks
+    // of chunk_spp, one lane per (pixel, chunk); chunk j draws from the streams keyed (pixel, samples_so_far + j*chunk_spp)
+    // and its radiance sum goes to partials[(j * blocks + block) * 256 + thread] = {sum.xyz, rand calls};
+    // terra_resolve_kernel then adds the chunk sums to the pixel IN CHUNK ORDER -- exactly what `split`
+    // successive calls of chunk_spp samples produce. split == 1: one kernel, no partials.
+    uint32_t split, split_log2, chunk_spp;
+    float4*  partials;
     uint32_t bounces;
     int32_t  integrator;
     int32_t  tonemap;

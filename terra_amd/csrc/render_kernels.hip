@@ -70,6 +70,44 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     return T;
 }
 
+// block (in launch order: own tile k, 16x16 block b inside it) and thread -> pixel; a wave covers 8x8 pixels
+TD bool block_pixel ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint32_t& px, uint32_t& py ) {
+    const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
+    const uint32_t k = blk / bpt2, b = blk - k * bpt2;
+    const uint32_t tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size;
+    const uint32_t t = p.rank + k * p.world;
+    const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+    const uint32_t bx = b % bpt, by = b / bpt;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t lx = tx * p.tile_size + bx * 16 + ( wave & 1 ) * 8 + ( lane & 7 );
+    const uint32_t ly = ty * p.tile_size + by * 16 + ( wave >> 1 ) * 8 + ( lane >> 3 );
+    px = p.x + lx; py = p.y + ly;
+    return lx < p.w && ly < p.h;
+}
+
+// Second kernel of a split render: pixel += chunk sums, in chunk order (float adds in the order `split`
+// successive calls would make them), then the same exposure / tonemap / store as the single-kernel path.
+__global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams p ) {
+    uint32_t px, py;
+    if ( !block_pixel ( p, blockIdx.x, threadIdx.x, px, py ) ) return;
+    const size_t pix = ( size_t ) py * p.fb_w + px;
+    DevResult* results = reinterpret_cast<DevResult*> ( p.results );
+    DevResult out = results[pix];
+    uint32_t calls = 0;
+    for ( uint32_t j = 0; j < p.split; ++j ) {
+        const float4 q = p.partials[ ( ( size_t ) j * gridDim.x + blockIdx.x ) * 256 + threadIdx.x];
+        out.acc[0] = out.acc[0] + q.x; out.acc[1] = out.acc[1] + q.y; out.acc[2] = out.acc[2] + q.z;
+        calls += __float_as_uint ( q.w );
+    }
+    out.samples = out.samples + ( int ) p.spp;
+    results[pix] = out;
+    float n = ( float ) out.samples;
+    V3 color = v3 ( out.acc[0] / n, out.acc[1] / n, out.acc[2] / n ) * p.exposure;
+    color = tonemap ( color, p.tonemap, p.gamma );
+    p.pixels[3 * pix + 0] = color.x; p.pixels[3 * pix + 1] = color.y; p.pixels[3 * pix + 2] = color.z;
+    if ( p.rand_calls ) p.rand_calls[pix] = calls;
+}
+
 // Occupancy target per integrator (second __launch_bounds__ argument = waves per SIMD = 256-thread
 // blocks per CU). Measured on MI355X (profiles/): the Simple/debug kernels run fastest at 5 even
 // with a small spill; Direct/MIS carry a second surface and more live state.
@@ -90,22 +128,15 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void
     const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
 
     // block -> (own tile, 16x16 block in tile) -> pixel
-    const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
-    const uint32_t k = blockIdx.x / bpt2, b = blockIdx.x - k * bpt2;
-    const uint32_t tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size;
-    const uint32_t t = p.rank + k * p.world;
-    const uint32_t tx = t % tiles_x, ty = t / tiles_x;
-    const uint32_t bx = b % bpt, by = b / bpt;
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    const uint32_t lx = tx * p.tile_size + bx * 16 + ( wave & 1 ) * 8 + ( lane & 7 );
-    const uint32_t ly = ty * p.tile_size + by * 16 + ( wave >> 1 ) * 8 + ( lane >> 3 );
-    const bool valid = lx < p.w && ly < p.h;
-    const uint32_t px = p.x + lx, py = p.y + ly;
+    // (with a sample split the consecutive blocks chunk 0..split-1 of one 16x16 pixel block)
+    const uint32_t chunk = blockIdx.x & ( p.split - 1 ), blk = blockIdx.x >> p.split_log2;
+    uint32_t px, py;
+    const bool valid = block_pixel ( p, blk, tid, px, py );
 
     DevResult* results = reinterpret_cast<DevResult*> ( p.results );
     // only the sample count is needed up front (it keys the streams); the running sum is re-read at the end
     const int prior_samples = valid ? results[ ( size_t ) py * p.fb_w + px].samples : 0;
-    PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples );
+    PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     Counters c = counters_zero();
 
     float* acc_lds = reinterpret_cast<float*> ( lds_f4 ) + ( p.stack_depth + p.leaf_cap ) * 256 + tid;     // acc.x/y/z at [0], [256], [512]
@@ -118,7 +149,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void
 
     while ( true ) {
         if ( !alive ) {
-            if ( !valid || s == p.spp ) break;
+            if ( !valid || s == p.chunk_spp ) break;
             float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
             ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
             Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++s;
@@ -152,7 +183,9 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void
         if ( end ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; alive = false; }
     }
 
-    if ( valid ) {
+    if ( p.split > 1 ) {      // this chunk's sum; terra_resolve_kernel folds the chunks into the pixel in order
+        p.partials[ ( ( size_t ) chunk * ( gridDim.x >> p.split_log2 ) + blk ) * 256 + tid] = make_float4 ( acc_lds[0], acc_lds[256], acc_lds[512], __uint_as_float ( COUNT == 2 ? c.rand_calls : 0u ) );
+    } else if ( valid ) {
         const size_t pix = ( size_t ) py * p.fb_w + px;
         const DevResult prior = results[pix];
         DevResult out;
@@ -227,7 +260,7 @@ static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t
 
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {
     uint32_t bpt = p.tile_size / 16;
-    uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt;
+    uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt * p.split;
     if ( blocks == 0 ) return hipSuccess;
     size_t lds = terra_lds_bytes ( p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
     switch ( p.integrator ) {
@@ -240,6 +273,17 @@ hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) 
         case 6: return launch_one<6> ( p, blocks, lds, stream );
         default: return hipErrorInvalidValue;
     }
+}
+
+uint32_t terra_render_blocks ( const DevRenderParams& p ) {
+    uint32_t bpt = p.tile_size / 16;
+    return own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt;
+}
+hipError_t terra_launch_resolve ( const DevRenderParams& p, hipStream_t stream ) {
+    uint32_t blocks = terra_render_blocks ( p );
+    if ( blocks == 0 ) return hipSuccess;
+    hipLaunchKernelGGL ( terra_resolve_kernel, dim3 ( blocks ), dim3 ( 256 ), 0, stream, p );
+    return hipGetLastError();
 }
 
 // ---- tile pack / unpack for the multi-GPU gather -------------------------------

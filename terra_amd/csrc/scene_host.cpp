@@ -238,6 +238,7 @@ struct Scene {
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
     int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree (terra_amd_set_tree_mode)
+    uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
@@ -276,6 +277,12 @@ extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
     return 0;
 }
 extern "C" int terra_amd_get_tree_mode ( HTerraScene h ) { return S ( h )->tree_mode; }
+extern "C" int terra_amd_set_sample_split ( HTerraScene h, int split ) {
+    if ( split != 1 && split != 2 && split != 4 && split != 8 && split != 16 ) return fail ( kTerraAmdErrBadArgument, "sample split %d: must be 1, 2, 4, 8 or 16", split );
+    S ( h )->sample_split = ( uint32_t ) split;
+    return 0;
+}
+extern "C" int terra_amd_get_sample_split ( HTerraScene h ) { return ( int ) S ( h )->sample_split; }
 extern "C" int terra_amd_set_environment_lighting ( HTerraScene h, int on ) {
     Scene* s = S ( h );
     if ( s->env_lighting != ( on != 0 ) ) { s->env_lighting = on != 0; s->dirty_lights = true; s->committed = false; }
@@ -840,6 +847,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.x = ( uint32_t ) x; p.y = ( uint32_t ) y; p.w = ( uint32_t ) w; p.h = ( uint32_t ) h;
     p.tile_size = ( uint32_t ) tile; p.rank = ( uint32_t ) rank; p.world = ( uint32_t ) world;
     p.spp = effective_spp ( s->opts );
+    p.split = 1; p.split_log2 = 0; p.chunk_spp = p.spp; p.partials = nullptr;
     p.bounces = ( uint32_t ) s->opts.bounces;
     p.integrator = ( int32_t ) s->opts.integrator; p.tonemap = ( int32_t ) s->opts.tonemapping_operator;
     if ( p.integrator < 0 || p.integrator > 6 ) return fail ( kTerraAmdErrBadArgument, "unknown integrator %d", p.integrator );
@@ -871,6 +879,31 @@ static void account_launch ( Scene* s, const DevRenderParams& p ) {
     ++s->launches; s->stat_pixels += px; s->stat_samples += px * p.spp;
 }
 
+// One render of p on `stream`: a single kernel, or -- with a sample split -- the chunk kernel into a
+// stream-ordered scratch buffer followed by the resolve kernel (DevRenderParams::split).
+static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
+    uint32_t split = s->sample_split;
+    while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
+    if ( split <= 1 ) { HIP_TRY ( terra_launch_render ( p, stream ), kTerraAmdErrLaunch ); return 0; }
+    const uint32_t blocks = terra_render_blocks ( p );
+    if ( blocks == 0 ) return 0;
+    static thread_local int pool_device = -1;
+    if ( pool_device != s->device ) {        // keep freed scratch cached in the device's default pool instead of returning it to the OS at every sync
+        hipMemPool_t pool;
+        if ( hipDeviceGetDefaultMemPool ( &pool, s->device ) == hipSuccess ) { uint64_t keep = ~0ull; ( void ) hipMemPoolSetAttribute ( pool, hipMemPoolAttrReleaseThreshold, &keep ); }
+        pool_device = s->device;
+    }
+    void* scratch = nullptr;
+    HIP_TRY ( hipMallocAsync ( &scratch, ( size_t ) split * blocks * 256 * sizeof ( float4 ), stream ), kTerraAmdErrNoDevice );
+    p.split = split; p.split_log2 = 0; while ( ( 1u << p.split_log2 ) < split ) ++p.split_log2;
+    p.chunk_spp = p.spp / split; p.partials = ( float4* ) scratch;
+    hipError_t e = terra_launch_render ( p, stream );
+    if ( e == hipSuccess ) e = terra_launch_resolve ( p, stream );
+    ( void ) hipFreeAsync ( scratch, stream );
+    if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "render launch: %s", hipGetErrorString ( e ) );
+    return 0;
+}
+
 extern "C" int terra_amd_render_device_sharded ( const TerraCamera* cam, HTerraScene h, void* d_pixels, void* d_results, size_t fb_w, size_t fb_h,
                                                  size_t x, size_t y, size_t w, size_t hgt, size_t tile, int rank, int world, void* d_rand_calls, void* stream ) {
     Scene* s = S ( h );
@@ -881,7 +914,7 @@ extern "C" int terra_amd_render_device_sharded ( const TerraCamera* cam, HTerraS
     p.pixels = ( float* ) d_pixels; p.results = d_results; p.rand_calls = ( uint32_t* ) d_rand_calls;
     if ( d_rand_calls ) p.count_level = 2;
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
-    HIP_TRY ( terra_launch_render ( p, ( hipStream_t ) stream ), kTerraAmdErrLaunch );
+    if ( int lrc = launch_render ( s, p, ( hipStream_t ) stream ) ) return lrc;
     account_launch ( s, p );
     return 0;
 }
@@ -982,7 +1015,7 @@ static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffe
     char* hpix = ( char* ) fb->pixels + ( y * fb->width + x ) * 12;
     HIP_TRY ( hipMemcpy2DAsync ( dres, rpitch, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, t.stream ), kTerraAmdErrLaunch );
     p.pixels = ( float* ) t.d_pixels; p.results = t.d_results; p.rand_calls = nullptr;
-    HIP_TRY ( terra_launch_render ( p, t.stream ), kTerraAmdErrLaunch );
+    if ( int lrc = launch_render ( s, p, t.stream ) ) return lrc;
     HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, dres, rpitch, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, dpix, ppitch, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipStreamSynchronize ( t.stream ), kTerraAmdErrLaunch );

@@ -52,6 +52,8 @@ _EXTRA = {
     "terra_amd_get_frame_seed": (C.c_uint64, [C.c_void_p]),
     "terra_amd_set_tree_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_tree_mode": (C.c_int, [C.c_void_p]),
+    "terra_amd_set_sample_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_get_sample_split": (C.c_int, [C.c_void_p]),
     "terra_amd_set_environment_lighting": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_environment_lighting": (C.c_int, [C.c_void_p]),
     "terra_amd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
