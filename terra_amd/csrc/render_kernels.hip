@@ -120,9 +120,20 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_WAVES_GENERIC      // Simple/debug kernels compiled for every preset, textures and the environment term (KINDS != diffuse-only)
 #define TERRA_WAVES_GENERIC TERRA_WAVES_SIMPLE
 #endif
-#define TERRA_WAVES_FOR(I, K) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
+// Decoupled traversal (see the kernel): scenes that are not LDS-resident, integrators whose shading casts no rays of its own
+#ifndef TERRA_DECOUPLED_ENABLE
+#define TERRA_DECOUPLED_ENABLE 1
+#endif
+#ifndef TERRA_DECOUPLED_EXIT_SHIFT      // leave the traversal when n >> shift of the n lanes that entered it have finished
+#define TERRA_DECOUPLED_EXIT_SHIFT 4
+#endif
+#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( M ) == 0 && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
+#ifndef TERRA_WAVES_DECOUPLED
+#define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
+#endif
+#define TERRA_WAVES_FOR(I, K, M) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : ( TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) ) )
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
-__global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void terra_render_kernel ( DevRenderParams p ) {
+__global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
     const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
@@ -144,9 +155,86 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     Ray ray = make_ray ( v3 ( 0, 0, 0 ), v3 ( 0, 0, 1 ) );
     uint32_t s = 0, bounce = 0;
-    bool alive = false;
     const V3 cam_pos = v3p ( p.cam_pos );
 
+    if constexpr ( TERRA_DECOUPLED ( INTEGRATOR, MODE ) ) {
+        // Decoupled loop (scenes read from global memory, integrators without nested raycasts): a lane is either
+        // traversing its current ray or waiting to be shaded. The resumable traversal returns as soon as a quarter of
+        // the lanes that entered it have finished; those are shaded and handed their next ray (continuation or the
+        // pixel's next camera sample) while the others keep their traversal state. Per pixel nothing changes: same
+        // rays, same stream draws, same accumulation order.
+        RayState st = ray_state_init ( ray );
+        Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
+        uint32_t best_rank = 0xffffffffu;      // MODE 2 only
+        int top = 0, nleaf = 0;
+        bool traversing = false, done = !valid, have_ray = false, regular = true;
+        for ( ;; ) {
+            if ( !traversing && !done ) {
+                bool next = false;
+                if ( have_ray ) {
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;           // the offset scene_raycast applies (src/Terra.c:1629-1630)
+                    if ( best.tri != 0xffffffffu ) {
+                        Surface sf;
+                        V3 point = r.o + r.d * best.depth;
+                        uint32_t object, tri_in_object, nattr;
+                        surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+                        if ( COUNT ) ++c.hits;
+                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+                        V3 wo = neg ( ray.d );
+                        Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, point, wo, throughput, bounce, rs.b, c );
+                        float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
+                        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+                        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
+                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
+                        throughput = had ( throughput, f );
+                        throughput = throughput * dot ( sf.normal, wi );
+                        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
+                        float e3 = randf ( rs.b, c, COUNT );
+                        if ( ! ( e3 > pr ) ) {
+                            throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+                            ray = surface_ray ( sf, point, wi, 1.f );
+                            ++bounce;
+                            next = bounce <= p.bounces;
+                        }
+                    } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {
+                        throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
+                        Lo = Lo + throughput;
+                    }
+                    if ( !next ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; }
+                }
+                if ( !next ) {
+                    if ( s == p.chunk_spp ) { done = true; have_ray = false; }
+                    else {
+                        float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
+                        ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
+                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; next = true;
+                    }
+                }
+                if ( next ) {
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;
+                    st = ray_state_init ( r );
+                    regular = ray_is_regular ( r );
+                    best.depth = FLT_MAX; best.tri = 0xffffffffu; best_rank = 0xffffffffu;
+                    T.stack[0] = 0; top = 1; nleaf = 0;
+                    traversing = true; have_ray = true;
+                    if ( COUNT ) ++c.rays;
+                }
+            }
+            const int n_trav = __popcll ( __ballot ( traversing ) );
+            if ( n_trav == 0 ) break;                // nobody traversing => everybody is done
+            int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+            const int exit_active = n_trav - quota;
+            Ray r = ray; r.o = r.o + r.d * 0.001f;
+            V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+            if ( MODE == 2 ) {
+                ClosestRanked b2; b2.depth = best.depth; b2.tri = best.tri; b2.rank = best_rank;
+                traverse_fast_resume<COUNT> ( T, r, st, o_perm, b2, top, traversing, exit_active, c );
+                best.depth = b2.depth; best.tri = b2.tri; best_rank = b2.rank;
+            } else if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            else traverse_resume<COUNT, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+        }
+    } else {
+    bool alive = false;
     while ( true ) {
         if ( !alive ) {
             if ( !valid || s == p.chunk_spp ) break;
@@ -181,6 +269,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS ) ) void
             Lo = Lo + throughput;
         }
         if ( end ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; alive = false; }
+    }
     }
 
     if ( p.split > 1 ) {      // this chunk's sum; terra_resolve_kernel folds the chunks into the pixel in order

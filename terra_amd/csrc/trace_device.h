@@ -408,6 +408,107 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
 }
 
 // -----------------------------------------------------------------------------
+// Resumable traversal for the decoupled render loop (large scenes; render_kernels.hip).
+// The 64 lanes of a wave hold DIFFERENT rays at different stages; a lane's traversal state
+// (stack column and leaf list in LDS; top, nleaf, closest hit in registers) survives leaving
+// and re-entering these functions. They return as soon as the number of lanes that still
+// have nodes to visit has dropped to `exit_active`, so that the finished lanes can be shaded
+// and given their next ray instead of idling until the slowest ray of the wave is done
+// (on the 97k-triangle hall a ray visits 474 nodes on average with a long tail: waiting for
+// the slowest of 64 left 17 % of the lanes busy). What is computed per ray, and in which
+// order, is exactly what traverse_loops / bvh_traverse_fast compute.
+// `traversing` is cleared for lanes whose traversal completed.
+// -----------------------------------------------------------------------------
+template <int COUNT, bool FAST>
+TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, int& top, int& nleaf, bool& traversing, int exit_active, Counters& c ) {
+    const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
+    const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
+    const int kx = st.ix, ky = st.iy, kz = st.iz;
+    for ( ;; ) {
+        for ( ;; ) {
+            const bool can = traversing && top > 0 && nleaf <= T.leaf_cap - 2;
+            if ( !__any ( can ) ) break;
+            if ( __popcll ( __ballot ( traversing && top > 0 ) ) <= exit_active ) break;
+            if ( can ) {
+                uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+                float4 q0 = g_nodes[4 * ni], q1 = g_nodes[4 * ni + 1], q2 = g_nodes[4 * ni + 2], q3 = g_nodes[4 * ni + 3];
+                uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+                if ( COUNT ) ++c.nodes;
+                bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
+                bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
+                bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
+                if ( !leaf0 && hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
+                if ( !leaf1 && hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
+                if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child0 & 0x7fffffffu ); ++nleaf; }
+                if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child1 & 0x7fffffffu ); ++nleaf; }
+            }
+        }
+        for ( int i = 0; i < nleaf; ++i ) {         // lanes that are not traversing hold nleaf == 0
+            uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
+            float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
+            V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+            float pa[3] = { pick ( va, kx ), pick ( va, ky ), pick ( va, kz ) };
+            float pb[3] = { pick ( vb, kx ), pick ( vb, ky ), pick ( vb, kz ) };
+            float pc[3] = { pick ( vc, kx ), pick ( vc, ky ), pick ( vc, kz ) };
+            if ( COUNT ) ++c.tri_tests;
+            float depth;
+            if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
+        }
+        nleaf = 0;
+        if ( traversing && top <= 0 ) traversing = false;
+        if ( __popcll ( __ballot ( traversing ) ) <= exit_active ) break;
+    }
+}
+
+template <int COUNT>
+TD void traverse_fast_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, ClosestRanked& best, int& top, bool& traversing, int exit_active, Counters& c ) {
+    const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
+    const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
+    for ( ;; ) {
+        const bool can = traversing && top > 0;
+        if ( __popcll ( __ballot ( can ) ) <= exit_active ) break;
+        if ( can ) {
+            uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+            float4 q0 = nodes[4 * ni], q1 = nodes[4 * ni + 1], q2 = nodes[4 * ni + 2], q3 = nodes[4 * ni + 3];
+            uint32_t child[2] = { __float_as_uint ( q3.x ), __float_as_uint ( q3.y ) };
+            if ( COUNT ) ++c.nodes;
+            float te[2];
+            bool hit[2];
+            hit[0] = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te[0] ) && te[0] <= best.depth && child[0] != DEV_CHILD_EMPTY;
+            hit[1] = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te[1] ) && te[1] <= best.depth && child[1] != DEV_CHILD_EMPTY;
+            #pragma unroll
+            for ( int k = 0; k < 2; ++k ) {
+                if ( hit[k] && ( child[k] & DEV_CHILD_LEAF ) ) {
+                    uint32_t first = child[k] & 0x07ffffffu, cnt = ( ( child[k] >> 27 ) & 0xfu ) + 1;
+                    for ( uint32_t j = 0; j < cnt; ++j ) {
+                        uint32_t ti = first + j;
+                        float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
+                        V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+                        float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
+                        float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
+                        float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
+                        if ( COUNT ) ++c.tri_tests;
+                        float depth;
+                        if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
+                            uint32_t rank = __float_as_uint ( cc.w );
+                            if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
+                        }
+                    }
+                }
+            }
+            bool in0 = hit[0] && ! ( child[0] & DEV_CHILD_LEAF ), in1 = hit[1] && ! ( child[1] & DEV_CHILD_LEAF );
+            if ( in0 && in1 ) {
+                bool zero_near = te[0] <= te[1];
+                T.stack[top * T.stride] = ( int ) ( zero_near ? child[1] : child[0] ); ++top;
+                T.stack[top * T.stride] = ( int ) ( zero_near ? child[0] : child[1] ); ++top;
+            } else if ( in0 ) { T.stack[top * T.stride] = ( int ) child[0]; ++top; }
+            else if ( in1 ) { T.stack[top * T.stride] = ( int ) child[1]; ++top; }
+        }
+    }
+    if ( traversing && top <= 0 ) traversing = false;
+}
+
+// -----------------------------------------------------------------------------
 // textures (reference src/Terra.c:368-466). uv is in TEXEL units, as the reference uses it
 // ((size_t)uv->x); three consecutive components are read whatever `components` says, as the
 // reference does; negative coordinates are undefined there and clamp to 0 here.
