@@ -127,7 +127,10 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_EXIT_SHIFT      // leave the traversal when n >> shift of the n lanes that entered it have finished
 #define TERRA_DECOUPLED_EXIT_SHIFT 4
 #endif
-#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( M ) == 0 && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
+#ifndef TERRA_DECOUPLED_LDS      // experiment: also decouple the LDS-resident (small scene) kernels
+#define TERRA_DECOUPLED_LDS 0
+#endif
+#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
 #ifndef TERRA_WAVES_DECOUPLED
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
@@ -230,8 +233,8 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 ClosestRanked b2; b2.depth = best.depth; b2.tri = best.tri; b2.rank = best_rank;
                 traverse_fast_resume<COUNT> ( T, r, st, o_perm, b2, top, traversing, exit_active, c );
                 best.depth = b2.depth; best.tri = b2.tri; best_rank = b2.rank;
-            } else if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
-            else traverse_resume<COUNT, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            } else if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
         }
     } else {
     bool alive = false;

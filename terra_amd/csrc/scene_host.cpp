@@ -635,17 +635,7 @@ static int upload_scene ( Scene* s ) {
     // child order only, never on node numbers, so results are unchanged.
     std::vector<uint32_t> bfs_of ( s->nodes.size(), 0 ), order;
     order.reserve ( s->nodes.size() );
-    const char* order_env = getenv ( "TERRA_AMD_NODE_ORDER" );
-    if ( order_env && strcmp ( order_env, "dfs" ) == 0 && !s->nodes.empty() ) {
-        // experiment: number nodes in the traversal's own visit order (child 1's subtree is popped first)
-        std::vector<uint32_t> st; st.push_back ( 0 );
-        while ( !st.empty() ) {
-            uint32_t n = st.back(); st.pop_back();
-            bfs_of[n] = ( uint32_t ) order.size(); order.push_back ( n );
-            const HostNode& h = s->nodes[n];
-            for ( int c = 0; c < 2; ++c ) if ( h.type[c] == -1 ) st.push_back ( ( uint32_t ) h.index[c] );
-        }
-    } else if ( !s->nodes.empty() ) {
+    if ( !s->nodes.empty() ) {
         order.push_back ( 0 );
         for ( size_t head = 0; head < order.size(); ++head ) {
             const HostNode& h = s->nodes[order[head]];

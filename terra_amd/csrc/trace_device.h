@@ -419,7 +419,7 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
 // order, is exactly what traverse_loops / bvh_traverse_fast compute.
 // `traversing` is cleared for lanes whose traversal completed.
 // -----------------------------------------------------------------------------
-template <int COUNT, bool FAST>
+template <int COUNT, int MODE, bool FAST>
 TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, int& top, int& nleaf, bool& traversing, int exit_active, Counters& c ) {
     const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
     const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
@@ -431,7 +431,9 @@ TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 
             if ( __popcll ( __ballot ( traversing && top > 0 ) ) <= exit_active ) break;
             if ( can ) {
                 uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
-                float4 q0 = g_nodes[4 * ni], q1 = g_nodes[4 * ni + 1], q2 = g_nodes[4 * ni + 2], q3 = g_nodes[4 * ni + 3];
+                float4 q0, q1, q2, q3;
+                if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
+                else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
                 uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
                 if ( COUNT ) ++c.nodes;
                 bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
@@ -445,11 +447,19 @@ TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 
         }
         for ( int i = 0; i < nleaf; ++i ) {         // lanes that are not traversing hold nleaf == 0
             uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
-            float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
-            V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
-            float pa[3] = { pick ( va, kx ), pick ( va, ky ), pick ( va, kz ) };
-            float pb[3] = { pick ( vb, kx ), pick ( vb, ky ), pick ( vb, kz ) };
-            float pc[3] = { pick ( vc, kx ), pick ( vc, ky ), pick ( vc, kz ) };
+            float pa[3], pb[3], pc[3];
+            if ( MODE == 1 ) {
+                const float* t = T.l_tris + 12 * ti;
+                pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
+                pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
+                pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
+            } else {
+                float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
+                V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+                pa[0] = pick ( va, kx ); pa[1] = pick ( va, ky ); pa[2] = pick ( va, kz );
+                pb[0] = pick ( vb, kx ); pb[1] = pick ( vb, ky ); pb[2] = pick ( vb, kz );
+                pc[0] = pick ( vc, kx ); pc[1] = pick ( vc, ky ); pc[2] = pick ( vc, kz );
+            }
             if ( COUNT ) ++c.tri_tests;
             float depth;
             if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
