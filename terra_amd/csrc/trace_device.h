@@ -427,8 +427,8 @@ TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 
     for ( ;; ) {
         for ( ;; ) {
             const bool can = traversing && top > 0 && nleaf <= T.leaf_cap - 2;
-            if ( !__any ( can ) ) break;
-            if ( __popcll ( __ballot ( traversing && top > 0 ) ) <= exit_active ) break;
+            const int n_can = __popcll ( __ballot ( can ) ), n_nodes = __popcll ( __ballot ( traversing && top > 0 ) );
+            if ( n_can == 0 || n_nodes <= exit_active ) break;
             if ( can ) {
                 uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
                 float4 q0, q1, q2, q3;

@@ -487,3 +487,26 @@ def test_scene_lifecycle_recommit_clear_and_many_objects(H, L, orc_lib, devmath_
         L.clear_error(); L.scene_commit(s2)
         assert (runtime.last_error() == "") == ok, (n, runtime.last_error())
         L.scene_destroy(s2)
+
+
+# ---------------------------------------------------------------------------
+# decoupled loop (scenes read from global memory, Simple/debug integrators): lanes of a wave are on
+# different rays; per pixel nothing may change
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,integ", [("spheres", 0), ("spheres", 4), ("spheres", 5), ("soup", 0), ("soup", 3), ("hall", 4)])
+def test_decoupled_loop_matches_the_oracle(H, L, orc_lib, devmath_mode, name, integ):
+    if name == "spheres":       # GGX + glass + diffuse: the generic kinds, 3,980 triangles, ragged frame, environment term on
+        d = scenes.cornell_spheres(104, 72, 3, integrator=integ, environment=(0.3, 0.4, 0.9), environment_lighting=True)
+    elif name == "hall":
+        d = scenes.sponza_hall(72, 40, 2, integrator=integ)
+    else:
+        from test_oracle_vs_reference import soup_scene
+        d = soup_scene(H, 1500, 33, integrator=integ); d.width, d.height, d.spp = 88, 56, 3
+    want = H.Unit("orc").render_pixels(d, passes=2)
+    got = render_dev(L, d, calls=True, passes=2)
+    assert same(H, got["pixels"], want["pixels"]) and same(H, got["acc"], want["acc"])
+    scene = scenes.build_scene(L, d)
+    info = runtime.SceneInfo(); runtime.check(L.scene_info(scene, C.byref(info)))
+    L.scene_destroy(scene)
+    assert info.triangles > 300, "must be a scene the LDS plan does not stage whole"
