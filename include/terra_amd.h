@@ -62,7 +62,9 @@ int  terra_amd_get_tree_mode ( HTerraScene scene );
    (each call of the reference sums its own samples and then adds them to the running sum,
    src/Terra.c:551-572). It exists for small tiles and shards: one GPU has more lanes than a 1/8 share
    of a 1080p frame has pixels. If spp is not a multiple of S the largest power of two dividing it is
-   used. A launch parameter: no commit needed. */
+   used. split = 0 picks S per call from the call's own size (enough blocks to fill the GPU about twice,
+   chunks of at least 16 samples): meant for clients that render in small tiles, as the reference's does
+   (128-pixel tiles, satellite/include/Config.hpp:25). A launch parameter: no commit needed. */
 int  terra_amd_set_sample_split ( HTerraScene scene, int split );
 int  terra_amd_get_sample_split ( HTerraScene scene );
 

@@ -278,7 +278,7 @@ extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
 }
 extern "C" int terra_amd_get_tree_mode ( HTerraScene h ) { return S ( h )->tree_mode; }
 extern "C" int terra_amd_set_sample_split ( HTerraScene h, int split ) {
-    if ( split != 1 && split != 2 && split != 4 && split != 8 && split != 16 ) return fail ( kTerraAmdErrBadArgument, "sample split %d: must be 1, 2, 4, 8 or 16", split );
+    if ( split != 0 && split != 1 && split != 2 && split != 4 && split != 8 && split != 16 ) return fail ( kTerraAmdErrBadArgument, "sample split %d: must be 0 (automatic), 1, 2, 4, 8 or 16", split );
     S ( h )->sample_split = ( uint32_t ) split;
     return 0;
 }
@@ -885,6 +885,13 @@ static void account_launch ( Scene* s, const DevRenderParams& p ) {
 // stream-ordered scratch buffer followed by the resolve kernel (DevRenderParams::split).
 static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
     uint32_t split = s->sample_split;
+    if ( split == 0 ) {
+        // automatic: enough blocks to fill the GPU about twice (256 CUs x 5 resident blocks), chunks of at least 16 samples.
+        // Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
+        const uint32_t blocks = terra_render_blocks ( p );
+        split = 1;
+        while ( split < 16 && blocks * split < 2560 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
+    }
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
     if ( split <= 1 ) { HIP_TRY ( terra_launch_render ( p, stream ), kTerraAmdErrLaunch ); return 0; }
     const uint32_t blocks = terra_render_blocks ( p );

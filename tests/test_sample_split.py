@@ -83,6 +83,13 @@ def test_split_against_the_oracle_and_accumulation(H, L, orc_lib):
     L.scene_destroy(scene)
 
 
+def test_automatic_split_is_a_function_of_the_call(H, L):
+    # 64x48 frame = 12 blocks: automatic picks 16 lanes per pixel at 256 spp (16 samples each), 2 at 32 spp, none at 16 spp
+    for spp, s in ((256, 16), (32, 2), (16, 1)):
+        mk = lambda n: scenes.cornell_box(64, 48, n)
+        assert same_fb(dev(L, mk(spp), split=0), dev(L, mk(spp // s), passes=s)), spp
+
+
 def test_split_falls_back_when_spp_is_not_a_multiple(H, L):
     # 12 spp with split 8 -> 4 chunks of 3; 7 spp -> no split at all
     assert same_fb(dev(L, scenes.cornell_box(48, 48, 12), split=8), dev(L, scenes.cornell_box(48, 48, 3), passes=4))
