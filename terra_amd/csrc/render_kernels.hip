@@ -168,7 +168,6 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // rays, same stream draws, same accumulation order.
         RayState st = ray_state_init ( ray );
         Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
-        uint32_t best_rank = 0xffffffffu;      // MODE 2 only
         int top = 0, nleaf = 0;
         bool traversing = false, done = !valid, have_ray = false, regular = true;
         for ( ;; ) {
@@ -217,7 +216,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
                     st = ray_state_init ( r );
                     regular = ray_is_regular ( r );
-                    best.depth = FLT_MAX; best.tri = 0xffffffffu; best_rank = 0xffffffffu;
+                    best.depth = FLT_MAX; best.tri = 0xffffffffu;
                     T.stack[0] = 0; top = 1; nleaf = 0;
                     traversing = true; have_ray = true;
                     if ( COUNT ) ++c.rays;
@@ -229,11 +228,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
             const int exit_active = n_trav - quota;
             Ray r = ray; r.o = r.o + r.d * 0.001f;
             V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-            if ( MODE == 2 ) {
-                ClosestRanked b2; b2.depth = best.depth; b2.tri = best.tri; b2.rank = best_rank;
-                traverse_fast_resume<COUNT> ( T, r, st, o_perm, b2, top, traversing, exit_active, c );
-                best.depth = b2.depth; best.tri = b2.tri; best_rank = b2.rank;
-            } else if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
             else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
         }
     } else {

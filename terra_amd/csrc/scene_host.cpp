@@ -428,6 +428,9 @@ static void build ( const TerraObject* objects, size_t nobj, std::vector<HostNod
 // ---- fast tree: 3-axis binned SAH, BVH2, leaves of <= 4 triangles ----------
 // Built over the same per-triangle boxes as the reference (triangle bounds +- 1e-4) so every
 // triangle a ray can hit lies inside its ancestors' boxes; inner boxes are plain unions.
+#ifndef TERRA_FAST_LEAF_MAX      // triangles per leaf of the fast tree (the leaf word holds count-1 in 4 bits)
+#define TERRA_FAST_LEAF_MAX 4
+#endif
 namespace fastbvh {
 struct Prim { TerraAABB box; float c[3]; uint32_t soup; };
 struct Built { std::vector<DevNode> nodes; std::vector<uint32_t> order; int max_stack = 1; };
@@ -466,7 +469,7 @@ static Built build ( std::vector<Prim>& prims ) {
     auto bounds = [&] ( int lo, int hi ) { TerraAABB b = empty(); for ( int i = lo; i < hi; ++i ) grow ( b, prims[i].box ); return b; };
     auto split = [&] ( int lo, int hi, int& mid ) -> bool {
         const int cnt = hi - lo;
-        if ( cnt <= 4 ) return false;
+        if ( cnt <= TERRA_FAST_LEAF_MAX ) return false;
         float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
         for ( int i = lo; i < hi; ++i ) for ( int a = 0; a < 3; ++a ) { cmin[a] = std::min ( cmin[a], prims[i].c[a] ); cmax[a] = std::max ( cmax[a], prims[i].c[a] ); }
         const int B = 16;

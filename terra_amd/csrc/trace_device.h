@@ -358,6 +358,9 @@ TD bool slab_enter ( V3 bmin, V3 bmax, const Ray& r, float& t_enter ) {
 
 struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
 
+// "while-while" form: leaves are pushed on the stack like inner nodes (near child last, so it is popped first);
+// a lane descends until it pops a leaf, then all lanes that hold one test its triangles together. Lanes no
+// longer wait, node after node, for neighbours that happen to be inside a leaf's triangle loop.
 template <int COUNT>
 TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
     const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
@@ -366,43 +369,40 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
     int top = 1;
     T.stack[0] = 0;
-    while ( top > 0 ) {
-        uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
-        float4 q0 = nodes[4 * ni], q1 = nodes[4 * ni + 1], q2 = nodes[4 * ni + 2], q3 = nodes[4 * ni + 3];
-        uint32_t child[2] = { __float_as_uint ( q3.x ), __float_as_uint ( q3.y ) };
-        if ( COUNT ) ++c.nodes;
-        float te[2];
-        bool hit[2];
-        hit[0] = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te[0] ) && te[0] <= best.depth && child[0] != DEV_CHILD_EMPTY;
-        hit[1] = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te[1] ) && te[1] <= best.depth && child[1] != DEV_CHILD_EMPTY;
-        #pragma unroll
-        for ( int k = 0; k < 2; ++k ) {
-            if ( hit[k] && ( child[k] & DEV_CHILD_LEAF ) ) {
-                uint32_t first = child[k] & 0x07ffffffu, cnt = ( ( child[k] >> 27 ) & 0xfu ) + 1;
-                for ( uint32_t j = 0; j < cnt; ++j ) {
-                    uint32_t ti = first + j;
-                    float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
-                    V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
-                    float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
-                    float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
-                    float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
-                    if ( COUNT ) ++c.tri_tests;
-                    float depth;
-                    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
-                        uint32_t rank = __float_as_uint ( cc.w );
-                        if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
-                    }
-                }
+    for ( ;; ) {
+        uint32_t leaf = 0;
+        while ( top > 0 ) {
+            uint32_t w = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+            if ( w & DEV_CHILD_LEAF ) { leaf = w; break; }
+            float4 q0 = nodes[4 * w], q1 = nodes[4 * w + 1], q2 = nodes[4 * w + 2], q3 = nodes[4 * w + 3];
+            uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+            if ( COUNT ) ++c.nodes;
+            float te0, te1;
+            bool hit0 = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te0 ) && te0 <= best.depth && child0 != DEV_CHILD_EMPTY;
+            bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;
+            if ( hit0 && hit1 ) {
+                bool zero_near = te0 <= te1;
+                T.stack[top * T.stride] = ( int ) ( zero_near ? child1 : child0 ); ++top;
+                T.stack[top * T.stride] = ( int ) ( zero_near ? child0 : child1 ); ++top;
+            } else if ( hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
+            else if ( hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
+        }
+        if ( !leaf ) break;
+        const uint32_t first = leaf & 0x07ffffffu, cnt = ( ( leaf >> 27 ) & 0xfu ) + 1;
+        for ( uint32_t j = 0; j < cnt; ++j ) {
+            uint32_t ti = first + j;
+            float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
+            V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+            float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
+            float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
+            float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
+            if ( COUNT ) ++c.tri_tests;
+            float depth;
+            if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
+                uint32_t rank = __float_as_uint ( cc.w );
+                if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
             }
         }
-        bool in0 = hit[0] && ! ( child[0] & DEV_CHILD_LEAF ), in1 = hit[1] && ! ( child[1] & DEV_CHILD_LEAF );
-        // far child first, so the near one is popped next
-        if ( in0 && in1 ) {
-            bool zero_near = te[0] <= te[1];
-            T.stack[top * T.stride] = ( int ) ( zero_near ? child[1] : child[0] ); ++top;
-            T.stack[top * T.stride] = ( int ) ( zero_near ? child[0] : child[1] ); ++top;
-        } else if ( in0 ) { T.stack[top * T.stride] = ( int ) child[0]; ++top; }
-        else if ( in1 ) { T.stack[top * T.stride] = ( int ) child[1]; ++top; }
     }
     return best;
 }
@@ -416,7 +416,7 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
 // and given their next ray instead of idling until the slowest ray of the wave is done
 // (on the 97k-triangle hall a ray visits 474 nodes on average with a long tail: waiting for
 // the slowest of 64 left 17 % of the lanes busy). What is computed per ray, and in which
-// order, is exactly what traverse_loops / bvh_traverse_fast compute.
+// order, is exactly what traverse_loops computes.
 // `traversing` is cleared for lanes whose traversal completed.
 // -----------------------------------------------------------------------------
 template <int COUNT, int MODE, bool FAST>
@@ -468,54 +468,6 @@ TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 
         if ( traversing && top <= 0 ) traversing = false;
         if ( __popcll ( __ballot ( traversing ) ) <= exit_active ) break;
     }
-}
-
-template <int COUNT>
-TD void traverse_fast_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, ClosestRanked& best, int& top, bool& traversing, int exit_active, Counters& c ) {
-    const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
-    const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
-    for ( ;; ) {
-        const bool can = traversing && top > 0;
-        if ( __popcll ( __ballot ( can ) ) <= exit_active ) break;
-        if ( can ) {
-            uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
-            float4 q0 = nodes[4 * ni], q1 = nodes[4 * ni + 1], q2 = nodes[4 * ni + 2], q3 = nodes[4 * ni + 3];
-            uint32_t child[2] = { __float_as_uint ( q3.x ), __float_as_uint ( q3.y ) };
-            if ( COUNT ) ++c.nodes;
-            float te[2];
-            bool hit[2];
-            hit[0] = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te[0] ) && te[0] <= best.depth && child[0] != DEV_CHILD_EMPTY;
-            hit[1] = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te[1] ) && te[1] <= best.depth && child[1] != DEV_CHILD_EMPTY;
-            #pragma unroll
-            for ( int k = 0; k < 2; ++k ) {
-                if ( hit[k] && ( child[k] & DEV_CHILD_LEAF ) ) {
-                    uint32_t first = child[k] & 0x07ffffffu, cnt = ( ( child[k] >> 27 ) & 0xfu ) + 1;
-                    for ( uint32_t j = 0; j < cnt; ++j ) {
-                        uint32_t ti = first + j;
-                        float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
-                        V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
-                        float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
-                        float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
-                        float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
-                        if ( COUNT ) ++c.tri_tests;
-                        float depth;
-                        if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
-                            uint32_t rank = __float_as_uint ( cc.w );
-                            if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
-                        }
-                    }
-                }
-            }
-            bool in0 = hit[0] && ! ( child[0] & DEV_CHILD_LEAF ), in1 = hit[1] && ! ( child[1] & DEV_CHILD_LEAF );
-            if ( in0 && in1 ) {
-                bool zero_near = te[0] <= te[1];
-                T.stack[top * T.stride] = ( int ) ( zero_near ? child[1] : child[0] ); ++top;
-                T.stack[top * T.stride] = ( int ) ( zero_near ? child[0] : child[1] ); ++top;
-            } else if ( in0 ) { T.stack[top * T.stride] = ( int ) child[0]; ++top; }
-            else if ( in1 ) { T.stack[top * T.stride] = ( int ) child[1]; ++top; }
-        }
-    }
-    if ( traversing && top <= 0 ) traversing = false;
 }
 
 // -----------------------------------------------------------------------------
