@@ -260,7 +260,8 @@ def main():
             "mrays_per_s": round(st["rays"] / max(1, st["launches"]) * (1 if world == 1 else world) / (kernel_ms * 1e-3) / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg), "rank0_only": world > 1},
+                         "algorithmic_bytes_per_launch": int(alg), "rank0_only": world > 1,
+                         "note": "achieved = algorithmic bytes (SURVEY 8d) / kernel time; it can exceed the HBM peak because a scene that fits is served from LDS (or L2 / Infinity Cache): `traffic` is what HBM actually moved"},
             "counters_per_launch": {k: v // max(1, st["launches"]) for k, v in st.items() if k != "launches"},
         }
         if check is not None:
