@@ -33,6 +33,26 @@ def write_obj(d, path, mirror_z=False):
                 vi += 3
 
 
+def write_obj_quads(d, path):
+    """same scene, written the way exporters do: shared vertex pool per object, quad faces (fan-triangulated by the
+    loader), relative (negative) indices, v/vt/vn triples, comments and blank lines"""
+    mtl = path.with_suffix(".mtl")
+    with open(path, "w") as f, open(mtl, "w") as m:
+        f.write(f"# quads + relative indices\n\nmtllib {mtl.name}\n")
+        for k, o in enumerate(d.objects):
+            mt = o.material
+            m.write(f"newmtl m{k}\nKd {mt.albedo[0]:.9g} {mt.albedo[1]:.9g} {mt.albedo[2]:.9g}\nKe {mt.emissive[0]:.9g} {mt.emissive[1]:.9g} {mt.emissive[2]:.9g}\n")
+            f.write(f"o obj{k}\nusemtl m{k}\n")
+            t, n = o.triangles, o.normals
+            assert len(t) % 2 == 0
+            for q in range(0, len(t), 2):
+                assert np.array_equal(t[q][0], t[q + 1][0]) and np.array_equal(t[q][2], t[q + 1][1])      # (a,b,c),(a,c,d)
+                corners = [(t[q][0], n[q][0]), (t[q][1], n[q][1]), (t[q][2], n[q][2]), (t[q + 1][2], n[q + 1][2])]
+                for p, nn in corners:
+                    f.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\nvt 0 0\nvn {nn[0]:.9g} {nn[1]:.9g} {nn[2]:.9g}\n")
+                f.write("f -4/-4/-4 -3/-3/-3 -2/-2/-2 -1/-1/-1\n")
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"
@@ -92,6 +112,26 @@ def test_tool_against_the_compiled_reference(H, ref_lib, tmp_path):
     assert np.array_equal(read_png(tmp_path / "img.png"), bytes_want)
     ppm = open(tmp_path / "img.ppm", "rb").read()
     assert ppm.startswith(b"P6\n80 60\n255\n") and np.array_equal(np.frombuffer(ppm[len(b"P6\n80 60\n255\n"):], np.uint8).reshape(60, 80, 3), bytes_want)
+
+
+def test_tool_quads_relative_indices_and_missing_files(H, ref_lib, tmp_path):
+    exe = build_tool(H, tmp_path, "ref")
+    d = scenes.cornell_box(64, 48, 1, integrator=api.kTerraIntegratorDebugDepth, jitter=0.0)
+    want = H.Unit("ref").render_pixels(d, want_calls=False)["pixels"]
+    obj = tmp_path / "quads.obj"; write_obj_quads(d, obj)
+    out = tmp_path / "q.pfm"
+    r = subprocess.run([str(exe), str(obj), str(out), "--width", "64", "--height", "48", "--spp", "1", "--integrator", "depth", "--tonemap", "none", "--no-flip-z"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "32 triangles" in r.stdout and np.array_equal(read_pfm(out), want)
+    # errors are reported, not crashed on
+    r = subprocess.run([str(exe), str(tmp_path / "missing.obj"), str(out)], capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot open" in r.stderr
+    (tmp_path / "empty.obj").write_text("# nothing\n")
+    r = subprocess.run([str(exe), str(tmp_path / "empty.obj"), str(out)], capture_output=True, text=True)
+    assert r.returncode != 0
+    # an unknown extension gets PNG, as the reference's exporter assumes (satellite/src/Visualization.cpp:313-316)
+    r = subprocess.run([str(exe), str(obj), str(tmp_path / "x.bmp"), "--width", "32", "--height", "24", "--spp", "1", "--integrator", "normals"], capture_output=True, text=True)
+    assert r.returncode == 0 and open(tmp_path / "x.bmp", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
 
 
 @pytest.mark.gpu
