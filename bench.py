@@ -65,6 +65,8 @@ def workload(name: str, spp_override):
         d = scenes.cornell_box(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorDirect)
     elif name == "hall_1080p_256spp":        # BASELINE.json configs[2]: ~100k triangles, deep reference-tree traversal
         d = scenes.sponza_hall(1920, 1080, 256, bounces=8, integrator=api.kTerraIntegratorSimple)
+    elif name == "hall_2160p_4096spp":       # BASELINE.json configs[4]: the 100k scene at 3840x2160, 4096 spp (meant for 8 GPUs)
+        d = scenes.sponza_hall(3840, 2160, 4096, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "spheres_1080p_1024spp":    # BASELINE.json configs[3]: glass + GGX spheres (this repo's presets; no reference behaviour)
         d = scenes.cornell_spheres(1920, 1080, 1024, bounces=8, integrator=api.kTerraIntegratorSimple)
     else:
