@@ -13,7 +13,12 @@
 //     iteration ("path regeneration"), so the traversal loop always runs with
 //     every lane that still has samples;
 //   * the traversal stack lives in LDS, one column per lane (conflict free),
-//     sized from the tree (max_stack entries, computed at commit).
+//     sized from the tree (max_stack entries, computed at commit);
+//   * with a sample split (DevRenderParams::split) a pixel's samples are cut into chunks that run on
+//     separate lanes (consecutive blocks), and terra_resolve_kernel folds the chunk sums into the pixel
+//     in order -- the framebuffer of `split` successive calls;
+//   * scenes that do not fit in LDS run the decoupled loop: a lane is either traversing its ray or
+//     waiting to be shaded, and the resumable traversal hands finished lanes back early.
 #include <hip/hip_runtime.h>
 #include "trace_device.h"
 #include "kernels.h"
@@ -127,7 +132,8 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_EXIT_SHIFT      // leave the traversal when n >> shift of the n lanes that entered it have finished
 #define TERRA_DECOUPLED_EXIT_SHIFT 4
 #endif
-#ifndef TERRA_DECOUPLED_LDS      // experiment: also decouple the LDS-resident (small scene) kernels
+#ifndef TERRA_DECOUPLED_LDS      // also decouple the LDS-resident (small scene) kernels: measured SLOWER (Cornell 26.7 -> 32 ms at best,
+                                // gpurun_out/ab_dec_lds.log): there shading outweighs traversal, so it stays off
 #define TERRA_DECOUPLED_LDS 0
 #endif
 #define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
