@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cornell_1080p_512spp")
+    ap.add_argument("--integrator", default="", choices=["", "simple", "direct", "mis"], help="override the workload's integrator (the result is then NOT the headline config)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
@@ -175,6 +176,8 @@ def main():
     runtime.check(lib.set_device(dev.index), "terra_amd_set_device")
 
     d = workload(args.workload, args.spp)
+    if args.integrator:
+        d.integrator = {"simple": api.kTerraIntegratorSimple, "direct": api.kTerraIntegratorDirect, "mis": api.kTerraIntegratorDirectMis}[args.integrator]
     scene = scenes.build_scene(lib, d, tree_mode=1 if args.tree == "fast" else 0)
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
@@ -257,7 +260,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces,
-                       "integrator": "simple" if d.integrator == 0 else ("direct" if d.integrator == 1 else str(d.integrator)),
+                       "integrator": {0: "simple", 1: "direct", 2: "mis"}.get(d.integrator, str(d.integrator)),
                        "triangles": d.triangle_count, "tree": args.tree, "tile": TILE, "sample_split": args.sample_split, "parallelism": f"tiles%{world}" if world > 1 else "single"},
             "mrays_per_s": round(st["rays"] / max(1, st["launches"]) * (1 if world == 1 else world) / (kernel_ms * 1e-3) / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
