@@ -156,19 +156,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
+    # the multi-rank code path; TERRA_BENCH_DIST1=1 takes it with ONE rank too (shard, pack, RCCL gather, unpack): a self-test of
+    # those calls on a 1-GPU box, never a benchmark
+    dist_on = world > 1 or os.environ.get("TERRA_BENCH_DIST1") == "1"
     ngpu = torch.cuda.device_count()
     if ngpu < 1:
         raise SystemExit("bench.py needs an MI355X")
     dev_index = (local_rank % ngpu) if world > 1 else 0        # ranks > GPUs only happens in a gloo rehearsal
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
-    via_host = world > 1 and args.dist_backend != "nccl"
+    via_host = dist_on and args.dist_backend != "nccl"
 
     lib = runtime.load()
     if lib.device_count() <= 0:
@@ -185,21 +188,21 @@ def main():
     cam = scenes.camera_of(d)
     fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
     n_packed = runtime.packed_floats_per_rank(d.width, d.height, TILE, world)
-    packed = torch.zeros(n_packed, dtype=torch.float32, device=dev) if world > 1 else None
-    gather_bufs = [torch.zeros(n_packed, dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    packed = torch.zeros(n_packed, dtype=torch.float32, device=dev) if dist_on else None
+    gather_bufs = [torch.zeros(n_packed, dtype=torch.float32, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None
     stream = torch.cuda.current_stream(dev).cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        if world == 1:
+        if not dist_on:
             runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, stream), "render")
         else:
             runtime.check(lib.render_device_sharded(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, None, stream), "render")
         if i is not None:
             ev[i][1].record()
-        if world > 1:
+        if dist_on:
             runtime.check(lib.pack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, packed.data_ptr(), stream), "pack")
             if via_host:
                 torch.cuda.synchronize(dev)
@@ -215,7 +218,7 @@ def main():
                     runtime.check(lib.unpack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, src, world, gather_bufs[src].data_ptr(), stream), "unpack")
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -228,7 +231,7 @@ def main():
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -271,12 +274,12 @@ def main():
         }
         if check is not None:
             out["sharded_equals_unsharded"] = check
-        if world > 1:
+        if dist_on:
             out["dist_backend"] = args.dist_backend
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
