@@ -133,7 +133,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #define TERRA_DECOUPLED_EXIT_SHIFT 4
 #endif
 #ifndef TERRA_DECOUPLED_LDS      // also decouple the LDS-resident (small scene) kernels: measured SLOWER (Cornell 26.7 -> 32 ms at best,
-                                // gpurun_out/ab_dec_lds.log): there shading outweighs traversal, so it stays off
+                                // profiles/r01_measurements/ab_dec_lds.log): there shading outweighs traversal, so it stays off
 #define TERRA_DECOUPLED_LDS 0
 #endif
 #define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
@@ -310,7 +310,7 @@ size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_n
 // Large scenes: nothing is staged -- their node fetches are bound by the L1 tag rate of divergent
 // 16-byte loads (each lane its own 64-B node) and by latency, so resident blocks matter most: the
 // leaf list takes what is left of the CU's 160 KB after fitting as many blocks as possible while
-// keeping at least 8 entries (gpurun_out/ab4.log, ab5.log: 4 blocks x 14 entries 219 ms vs
+// keeping at least 8 entries (profiles/r01_measurements/ab4.log, ab5.log: 4 blocks x 14 entries 219 ms vs
 // 3 blocks x 16 entries 305 ms vs 4-entry lists 261 ms on the 97k-triangle hall).
 #ifndef TERRA_LDS_CU_KB
 #define TERRA_LDS_CU_KB 158
