@@ -114,3 +114,33 @@ def test_split_with_shards_rectangles_and_host_entry(H, L):
     assert L.set_sample_split(scene, 3) < 0 and "sample split" in runtime.last_error()
     L.clear_error()
     fb.destroy(); L.scene_destroy(scene)
+
+
+def test_threaded_tile_calls_with_automatic_split(H, L):
+    """the reference client's pattern: worker threads call terra_render() on disjoint tiles of one framebuffer; with the
+    automatic split every call picks its own lanes-per-pixel, and the frame must not depend on threads or call order"""
+    import threading
+    d = scenes.cornell_box(192, 128, 64, integrator=api.kTerraIntegratorDirect)
+    tiles = [(x, y, min(64, d.width - x), min(48, d.height - y)) for y in range(0, d.height, 48) for x in range(0, d.width, 64)]
+    frames = []
+    for threaded in (False, True):
+        scene = scenes.build_scene(L, d); assert L.set_sample_split(scene, 0) == 0
+        fb = api.Framebuffer(L, d.width, d.height); cam = scenes.camera_of(d)
+        L.clear_error()
+        if threaded:
+            def work(k):
+                for t in tiles[k::4][::-1]:
+                    L.render(C.byref(cam), scene, C.byref(fb.fb), *t)
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+            [t.start() for t in ths]; [t.join() for t in ths]
+        else:
+            for t in tiles:
+                L.render(C.byref(cam), scene, C.byref(fb.fb), *t)
+        assert runtime.last_error() == ""
+        frames.append((fb.results["acc"].copy(), fb.pixels.copy(), fb.results["samples"].copy()))
+        fb.destroy(); L.scene_destroy(scene)
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32)) and np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))
+    assert (frames[0][2] == 64).all()
+    # a 64x48 tile is 12 blocks: the automatic rule gives 4 lanes per pixel at 64 spp (16 samples each) = 4 calls of 16
+    want = dev(L, scenes.cornell_box(192, 128, 16, integrator=api.kTerraIntegratorDirect), passes=4)
+    assert np.array_equal(frames[0][0].view(np.uint32), want["acc"].view(np.uint32))
