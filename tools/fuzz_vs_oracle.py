@@ -1,0 +1,72 @@
+"""Randomised device-vs-oracle run on the GPU (not a unit test): random triangle soups (2..2500 triangles, so all three
+kernel layouts: LDS-resident, global/decoupled, fast tree), random preset mixes incl. Phong / GGX / glass, all seven
+integrators, random sample splits. The device image must equal the oracle's (device-twin math) bit for bit (NaNs: same
+positions), and the fast tree must equal the reference tree.
+    python tools/fuzz_vs_oracle.py [iterations] [seed]"""
+import torch  # first
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from terra_amd import api, runtime, scenes
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+lib = runtime.load()
+orc = api.TerraLib(os.path.join(ROOT, "oracle", "liboracle.so"), "orc_")
+orc.fn("orc_set_math_mode", None, [C.c_int])(1)
+orp = orc.fn("orc_render_pixels", None, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 4 + [C.c_uint64, C.c_void_p])
+
+
+def soup(n_tris, n_objects):
+    objs = []
+    per = max(1, n_tris // n_objects); left = n_tris
+    for k in range(n_objects):
+        n = per if k < n_objects - 1 else left
+        if n <= 0: break
+        left -= n
+        c = rs.uniform(-2, 2, size=(n, 1, 3)); tris = (c + rs.uniform(-0.5, 0.5, size=(n, 3, 3))).astype(np.float32)
+        e1 = tris[:, 1] - tris[:, 0]; e2 = tris[:, 2] - tris[:, 0]
+        nrm = np.cross(e1, e2); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+        nrm = np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)
+        kind = str(rs.choice(["diffuse", "diffuse", "phong", "ggx", "glass"]))
+        m = scenes.Material(kind=kind, albedo=tuple(rs.uniform(0.2, 0.9, 3)), emissive=(4.0, 3.0, 2.0) if k == 0 else (0.0, 0.0, 0.0),
+                            specular_color=tuple(rs.uniform(0.1, 0.9, 3)), specular_intensity=float(rs.choice([1.0, 8.0, 30.5])), roughness=float(rs.uniform(0.05, 0.9)), ior=1.5)
+        objs.append(scenes.ObjectDesc(tris, nrm, rs.uniform(0, 1, size=(n, 3, 2)).astype(np.float32), m))
+    return objs
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
+
+
+bad = 0
+for it in range(n_iter):
+    n = int(rs.choice([2, 9, 40, 150, 400, 1200, 2500])); W, H = int(rs.randint(20, 70)), int(rs.randint(16, 50))
+    integ = int(rs.randint(0, 7)); split = int(rs.choice([1, 1, 2, 4])); spp = split * int(rs.randint(1, 3))
+    d = scenes.SceneDesc(objects=soup(n, int(rs.randint(1, 5))), width=W, height=H, spp=spp, bounces=int(rs.randint(0, 6)), integrator=integ,
+                         camera_position=(0.0, 0.0, -6.0), tonemap=int(rs.randint(0, 5)), environment=(0.2, 0.3, 0.4), environment_lighting=bool(rs.randint(2)))
+    cam = scenes.camera_of(d)
+    so = scenes.build_scene(orc, d); fo = api.Framebuffer(orc, W, H)
+    dchunk = scenes.SceneDesc(**{**d.__dict__, "spp": spp // split}); sc = scenes.build_scene(orc, dchunk)
+    for _ in range(split):
+        orp(C.byref(cam), sc, C.byref(fo.fb), 0, 0, W, H, scenes.FRAME_SEED, None)
+    outs = []
+    for tree in (0, 1):
+        lib.clear_error()
+        s = scenes.build_scene(lib, d, tree_mode=tree); runtime.check(lib.set_sample_split(s, split))
+        fb = runtime.DeviceFramebuffer(W, H)
+        runtime.check(lib.render_device(C.byref(cam), s, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, None, None))
+        torch.cuda.synchronize()
+        outs.append((fb.results_host()["acc"].copy(), fb.pixels_host().copy()))
+        lib.scene_destroy(s)
+    ok0 = bits_equal(outs[0][0], fo.results["acc"]) and bits_equal(outs[0][1], fo.pixels)
+    ok1 = bits_equal(outs[1][0], outs[0][0]) and bits_equal(outs[1][1], outs[0][1])
+    if not (ok0 and ok1):
+        bad += 1; print("MISMATCH", dict(it=it, tris=n, W=W, H=H, integ=integ, split=split, spp=spp, bounces=d.bounces, tonemap=d.tonemap, env=d.environment_lighting, vs_oracle=ok0, fast_vs_ref=ok1,
+                                         kinds=[o.material.kind for o in d.objects]))
+    fo.destroy(); orc.scene_destroy(so); orc.scene_destroy(sc)
+print(f"{n_iter} cases, {bad} mismatches, last error: '{runtime.last_error()}'")
+sys.exit(1 if bad else 0)
