@@ -47,7 +47,8 @@ for it in range(n_iter):
     n = int(rs.choice([2, 9, 40, 150, 400, 1200, 2500])); W, H = int(rs.randint(20, 70)), int(rs.randint(16, 50))
     integ = int(rs.randint(0, 7)); split = int(rs.choice([1, 1, 2, 4])); spp = split * int(rs.randint(1, 3))
     d = scenes.SceneDesc(objects=soup(n, int(rs.randint(1, 5))), width=W, height=H, spp=spp, bounces=int(rs.randint(0, 6)), integrator=integ,
-                         camera_position=(0.0, 0.0, -6.0), tonemap=int(rs.randint(0, 5)), environment=(0.2, 0.3, 0.4), environment_lighting=bool(rs.randint(2)))
+                         camera_position=(0.0, 0.0, -6.0), tonemap=int(rs.randint(0, 5)), environment=(0.2, 0.3, 0.4), environment_lighting=bool(rs.randint(2)),
+                         jitter=float(rs.choice([0.0, 0.5])))      # jitter 0 on odd frame sizes gives rays with exactly zero direction components (the exact slab path)
     cam = scenes.camera_of(d)
     so = scenes.build_scene(orc, d); fo = api.Framebuffer(orc, W, H)
     dchunk = scenes.SceneDesc(**{**d.__dict__, "spp": spp // split}); sc = scenes.build_scene(orc, dchunk)
