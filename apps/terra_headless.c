@@ -17,7 +17,7 @@
  *   terra_headless scene.obj out.png [--width W] [--height H] [--spp N] [--bounces N]
  *       [--integrator simple|direct|mis|normals|depth] [--tonemap none|linear|reinhard|filmic|uncharted2]
  *       [--camera px py pz dx dy dz] [--fov deg] [--exposure e] [--gamma g] [--jitter j]
- *       [--no-flip-z] [--fast-tree] [--seed n] [--tile n]
+ *       [--no-flip-z] [--fast-tree | --auto-tree] [--sample-split n] [--seed n] [--tile n]
  */
 #include <ctype.h>
 #include <stdio.h>
@@ -28,6 +28,7 @@
 
 const char* terra_amd_last_error ( void ) __attribute__ ( ( weak ) );
 int         terra_amd_set_tree_mode ( HTerraScene, int ) __attribute__ ( ( weak ) );
+int         terra_amd_set_sample_split ( HTerraScene, int ) __attribute__ ( ( weak ) );
 void        terra_amd_set_frame_seed ( HTerraScene, uint64_t ) __attribute__ ( ( weak ) );
 
 /* ---- growable arrays ------------------------------------------------------------------------ */
@@ -258,7 +259,7 @@ static int pick ( const char* v, const char* const* names, int n, int dflt ) { f
 int main ( int argc, char** argv ) {
     if ( argc < 3 ) { fprintf ( stderr, "usage: terra_headless scene.obj out.{png,ppm,pfm,hdr} [options]\n" ); return 64; }
     size_t W = 800, H = 600, spp = 8, bounces = 4, tile = 0;     /* defaults of satellite/include/Config.hpp:19-113 */
-    int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = 0, have_seed = 0;
+    int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = 0, have_seed = 0, split = -1;
     float fov = 45.f, exposure = 1.f, gamma = 2.2f, jitter = 0.f;
     unsigned long long seed = 0;
     TerraCamera cam; cam.position = terra_f3_set ( 0.f, 1.f, -3.4f ); cam.direction = terra_f3_set ( 0.f, 0.f, 1.f ); cam.up = terra_f3_set ( 0.f, 1.f, 0.f );
@@ -277,6 +278,8 @@ int main ( int argc, char** argv ) {
         else if ( !strcmp ( a, "--seed" ) ) { seed = strtoull ( NEXT(), NULL, 0 ); have_seed = 1; }
         else if ( !strcmp ( a, "--no-flip-z" ) ) flip = 0;
         else if ( !strcmp ( a, "--fast-tree" ) ) fast = 1;
+        else if ( !strcmp ( a, "--auto-tree" ) ) fast = 2;
+        else if ( !strcmp ( a, "--sample-split" ) ) split = atoi ( NEXT() );
         else if ( !strcmp ( a, "--integrator" ) ) { static const char* const n[] = { "simple", "direct", "mis", "mono", "depth", "normals", "misweights" }; integrator = pick ( NEXT(), n, 7, integrator ); }
         else if ( !strcmp ( a, "--tonemap" ) ) { static const char* const n[] = { "none", "linear", "reinhard", "filmic", "uncharted2" }; tonemap = pick ( NEXT(), n, 5, tonemap ); }
         else if ( !strcmp ( a, "--camera" ) && i + 6 < argc ) {
@@ -294,7 +297,8 @@ int main ( int argc, char** argv ) {
     o->tonemapping_operator = ( TerraTonemappingOperator ) tonemap; o->accelerator = kTerraAcceleratorBVH; o->sampling_method = kTerraSamplingMethodRandom;
     o->integrator = ( TerraIntegrator ) integrator; o->subpixel_jitter = jitter; o->samples_per_pixel = spp; o->bounces = bounces; o->strata = 4;
     o->manual_exposure = exposure; o->gamma = gamma;
-    if ( fast && terra_amd_set_tree_mode ) terra_amd_set_tree_mode ( scene, 1 );
+    if ( fast && terra_amd_set_tree_mode ) terra_amd_set_tree_mode ( scene, fast );
+    if ( split >= 0 && terra_amd_set_sample_split ) terra_amd_set_sample_split ( scene, split );
     if ( have_seed && terra_amd_set_frame_seed ) terra_amd_set_frame_seed ( scene, seed );
     terra_scene_commit ( scene );
     TerraFramebuffer fb;

@@ -51,7 +51,8 @@ uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
    src/TerraBVH.c:79-244) traversed in the reference's order: the parity mode. 1 = "fast tree": a
    3-axis binned-SAH BVH2 over the same triangles with ordered, culled traversal; ties in depth are
    resolved by the reference tree's leaf visit order, so it selects the same triangle as mode 0
-   (DESIGN.md "Fast tree"). Takes effect at the next terra_scene_commit(). */
+   (DESIGN.md "Fast tree"). 2 = automatic: the reference tree when the whole scene is staged in
+   LDS (there it is the faster of the two), the fast tree otherwise. Takes effect at the next terra_scene_commit(). */
 int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
 int  terra_amd_get_tree_mode ( HTerraScene scene );
 

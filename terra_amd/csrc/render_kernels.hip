@@ -318,13 +318,16 @@ size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_n
 #ifndef TERRA_LDS_BUDGET
 #define TERRA_LDS_BUDGET ( 32 * 1024 )
 #endif
+bool terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack ) {
+    const uint32_t depth = max_stack < 1 ? 1u : ( uint32_t ) max_stack;
+    return ( size_t ) ( depth + TERRA_LEAF_CAP_MAX + TERRA_AUX_WORDS ) * 1024 + ( size_t ) n_nodes * 64 + ( size_t ) n_tris * 112 <= ( size_t ) TERRA_LDS_BUDGET;
+}
 void terra_plan_lds ( DevRenderParams& p ) {
     const size_t budget = TERRA_LDS_BUDGET;
     uint32_t depth = p.scene.max_stack < 1 ? 1u : ( uint32_t ) p.scene.max_stack;
     p.stack_depth = depth;
     p.leaf_cap = TERRA_LEAF_CAP_MAX;
-    size_t whole = ( size_t ) p.scene.n_nodes * 64 + ( size_t ) p.scene.n_tris * 112;
-    if ( ( size_t ) ( depth + TERRA_LEAF_CAP_MAX + TERRA_AUX_WORDS ) * 1024 + whole <= budget ) {
+    if ( terra_scene_fits_lds ( p.scene.n_nodes, p.scene.n_tris, p.scene.max_stack ) ) {
         p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris;
         return;
     }

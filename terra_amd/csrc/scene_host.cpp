@@ -237,7 +237,8 @@ struct Scene {
     uint64_t launches = 0, stat_pixels = 0, stat_samples = 0;
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
-    int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree (terra_amd_set_tree_mode)
+    int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree, 2 = fast tree unless the scene is LDS-resident
+    bool use_fast = false;              // what the last upload decided
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
@@ -271,7 +272,7 @@ extern "C" TerraObject* terra_scene_add_object ( HTerraScene h, size_t n ) {
 extern "C" size_t terra_scene_count_objects ( HTerraScene h ) { return S ( h )->objects_pop; }
 extern "C" TerraSceneOptions* terra_scene_get_options ( HTerraScene h ) { return &S ( h )->new_opts; }
 extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
-    if ( mode != 0 && mode != 1 ) return fail ( kTerraAmdErrBadArgument, "tree mode %d (0 = reference tree, 1 = fast tree)", mode );
+    if ( mode != 0 && mode != 1 && mode != 2 ) return fail ( kTerraAmdErrBadArgument, "tree mode %d (0 = reference tree, 1 = fast tree, 2 = automatic)", mode );
     Scene* s = S ( h );
     if ( s->tree_mode != mode ) { s->tree_mode = mode; s->dirty_objects = true; s->committed = false; }
     return 0;
@@ -661,7 +662,8 @@ static int upload_scene ( Scene* s ) {
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
     std::vector<DevNode> fnodes; std::vector<DevTri> ftris;
     s->fast_nodes = 0; s->fast_max_stack = 1;
-    if ( s->tree_mode == 1 ) {
+    s->use_fast = s->tree_mode == 1 || ( s->tree_mode == 2 && !terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack ) );
+    if ( s->use_fast ) {
         // rank of every soup triangle in the reference traversal's leaf visit order (all boxes hit)
         std::vector<uint32_t> rank ( ntri ? ntri : 1, 0 );
         {
@@ -861,7 +863,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.frame_seed = s->frame_seed;
     p.counters = s->d_counters;
     terra_plan_lds ( p );
-    if ( s->tree_mode == 1 && s->dev.fast_nodes ) { p.lds_mode = 2; p.lds_nodes = 0; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) s->dev.fast_max_stack; }
+    if ( s->use_fast && s->dev.fast_nodes ) { p.lds_mode = 2; p.lds_nodes = 0; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) s->dev.fast_max_stack; }
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;
     p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;

@@ -489,6 +489,17 @@ def test_scene_lifecycle_recommit_clear_and_many_objects(H, L, orc_lib, devmath_
         L.scene_destroy(s2)
 
 
+def test_automatic_tree_mode_picks_by_scene_size(H, L):
+    """mode 2: the reference tree for LDS-resident scenes, the fast tree otherwise; same image either way"""
+    for mk, expect_fast in ((lambda: scenes.cornell_box(64, 48, 2), False), (lambda: scenes.cornell_spheres(64, 48, 2), True)):
+        ref, fast, auto = (render_dev(L, mk(), tree_mode=m) for m in (0, 1, 2))
+        assert same(H, auto["pixels"], ref["pixels"]) and same(H, fast["pixels"], ref["pixels"])
+        assert auto["stats"]["nodes"] == (fast if expect_fast else ref)["stats"]["nodes"]
+    scene = L.scene_create()
+    assert L.set_tree_mode(scene, 3) < 0
+    L.clear_error(); L.scene_destroy(scene)
+
+
 # ---------------------------------------------------------------------------
 # decoupled loop (scenes read from global memory, Simple/debug integrators): lanes of a wave are on
 # different rays; per pixel nothing may change
