@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_set>
+#include <atomic>
 #include <vector>
 
 #include "../../include/terra_amd.h"
@@ -234,7 +235,7 @@ struct Scene {
     // device replica
     DevScene dev; void* d_blob = nullptr; size_t d_bytes = 0;
     unsigned long long* d_counters = nullptr;
-    uint64_t launches = 0, stat_pixels = 0, stat_samples = 0;
+    std::atomic<uint64_t> launches { 0 }, stat_pixels { 0 }, stat_samples { 0 };     // terra_render() is called from several threads at once
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
     int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree, 2 = fast tree unless the scene is LDS-resident
@@ -883,7 +884,7 @@ static uint64_t shard_pixels ( const DevRenderParams& p ) {
 }
 static void account_launch ( Scene* s, const DevRenderParams& p ) {
     uint64_t px = shard_pixels ( p );
-    ++s->launches; s->stat_pixels += px; s->stat_samples += px * p.spp;
+    s->launches.fetch_add ( 1, std::memory_order_relaxed ); s->stat_pixels.fetch_add ( px, std::memory_order_relaxed ); s->stat_samples.fetch_add ( px * p.spp, std::memory_order_relaxed );
 }
 
 // One render of p on `stream`: a single kernel, or -- with a sample split -- the chunk kernel into a
