@@ -96,6 +96,9 @@ typedef struct {
 } TerraAmdStats;
 int terra_amd_get_stats ( HTerraScene scene, TerraAmdStats* out );
 int terra_amd_reset_stats ( HTerraScene scene );
+/* Debug builds only (-DTERRA_CHECK_BOUNDS=1 verifies every traversal-stack and leaf-list write against the sizes
+   the host planned): number of writes refused since the last reset; the shipped build always reports 0. -1 = no device. */
+long long terra_amd_debug_faults ( HTerraScene scene );
 
 /* Flattened-scene facts after commit (for tests and the roofline model). */
 typedef struct {

@@ -42,6 +42,12 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
     objdir.mkdir(exist_ok=True)
     OUT = HERE / (f"libterra_amd_{variant}.so" if variant else "libterra_amd.so")
     deps_common = [CSRC / h for h in HEADERS] + [HERE.parent / "include" / h for h in ("Terra.h", "TerraMath.h", "TerraPresets.h", "terra_amd.h")] + [Path(__file__)]
+    # a change of flags (experiment builds are re-run with different -D values) invalidates the objects too
+    stamp = objdir / "flags.txt"
+    flags_now = " ".join([*FLAGS, *extra_flags])
+    objdir.mkdir(parents=True, exist_ok=True)
+    if not stamp.exists() or stamp.read_text() != flags_now:
+        force = True
     jobs = []
     for src in SOURCES:
         obj = objdir / (src + ".o")
@@ -63,6 +69,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(compile_one, jobs))
+    stamp.write_text(flags_now)
     objs = [objdir / (s + ".o") for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", str(OUT), *map(str, objs)]

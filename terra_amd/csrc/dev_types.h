@@ -114,7 +114,7 @@ struct DevScene {
 #define TERRA_KIND_TEX 32
 
 // indices into the device counter array (uint64 each); mirrors TerraAmdStats
-enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrCount };
+enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrFaults, kCtrCount };   // kCtrFaults: only written by TERRA_CHECK_BOUNDS builds
 
 struct DevRenderParams {
     DevScene scene;

@@ -50,6 +50,9 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t
 // per-thread words parked in LDS between uses (indexed [word][thread] like the stack): the pixel's
 // radiance sum of this call, touched once per path
 #define TERRA_AUX_WORDS 3
+#ifndef TERRA_CHECK_SHRINK
+#define TERRA_CHECK_SHRINK 0
+#endif
 TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
     const int tid = threadIdx.x;
     Tracer T;
@@ -59,6 +62,8 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.leaves = words + stack_depth * 256 + tid;
     T.stride = 256;
     T.leaf_cap = ( int ) leaf_cap;
+    T.stack_cap = ( int ) stack_depth - TERRA_CHECK_SHRINK;      // TERRA_CHECK_SHRINK > 0: positive control of the bounds check
+    T.faults = nullptr;
     float4* stage = lds + ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 64;
     float4* ln = stage;
     float4* lt = ln + 4 * lds_nodes;
@@ -145,7 +150,9 @@ template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
-    const Tracer T = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
+    Tracer T0 = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
+    T0.faults = p.counters + kCtrFaults;
+    const Tracer T = T0;
 
     // block -> (own tile, 16x16 block in tile) -> pixel
     // (with a sample split the consecutive blocks chunk 0..split-1 of one 16x16 pixel block)

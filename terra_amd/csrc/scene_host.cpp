@@ -809,6 +809,14 @@ extern "C" int terra_amd_get_stats ( HTerraScene h, TerraAmdStats* out ) {
     out->samples = s->stat_samples; out->pixels = s->stat_pixels; out->launches = s->launches;
     return 0;
 }
+extern "C" long long terra_amd_debug_faults ( HTerraScene h ) {
+    // out-of-plan stack / leaf-list writes refused by a TERRA_CHECK_BOUNDS build since the last reset (always 0 in the shipped build)
+    Scene* s = S ( h );
+    if ( !s->device_ok ) return -1;
+    unsigned long long v = 0;
+    if ( hipSetDevice ( s->device ) != hipSuccess || hipMemcpy ( &v, s->d_counters + kCtrFaults, sizeof v, hipMemcpyDeviceToHost ) != hipSuccess ) return -1;
+    return ( long long ) v;
+}
 extern "C" int terra_amd_reset_stats ( HTerraScene h ) {
     Scene* s = S ( h );
     if ( !s->device_ok ) return fail ( kTerraAmdErrNotCommitted, "scene has no device replica" );

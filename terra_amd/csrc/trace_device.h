@@ -202,6 +202,8 @@ struct Tracer {
     int*          leaves;
     int           stride;      // 256
     int           leaf_cap;    // entries in the leaf list (>= 2)
+    int           stack_cap;   // entries in the stack column (TERRA_CHECK_BOUNDS builds verify every push against it)
+    unsigned long long* faults;
 };
 
 // -----------------------------------------------------------------------------
@@ -279,6 +281,15 @@ TD bool watertight_permuted ( const float pa[3], const float pb[3], const float 
 // -----------------------------------------------------------------------------
 struct Closest { float depth; uint32_t tri; };
 
+// Stack / leaf-list writes. A TERRA_CHECK_BOUNDS build (python -m terra_amd.build --variant chk -DTERRA_CHECK_BOUNDS=1)
+// refuses (drops the entry, so the column is never left) and counts any write beyond the sizes the host planned; the shipped build trusts the plan
+// (max_stack is the exact worst case of the tree, computed at commit).
+#ifndef TERRA_CHECK_BOUNDS
+#define TERRA_CHECK_BOUNDS 0
+#endif
+#define TERRA_PUSH(T, top, v) do { if ( TERRA_CHECK_BOUNDS && ( top ) >= ( T ).stack_cap ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { ( T ).stack[ ( top ) * ( T ).stride] = ( int ) ( v ); ++( top ); } } while ( 0 )
+#define TERRA_LEAF(T, n, v) do { if ( TERRA_CHECK_BOUNDS && ( n ) >= ( T ).leaf_cap ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { ( T ).leaves[ ( n ) * ( T ).stride] = ( int ) ( v ); ++( n ); } } while ( 0 )
+
 template <int COUNT, int MODE, bool FAST>
 TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
     const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
@@ -297,10 +308,10 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
             bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
             bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
             bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
-            if ( !leaf0 && hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
-            if ( !leaf1 && hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
-            if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child0 & 0x7fffffffu ); ++nleaf; }
-            if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child1 & 0x7fffffffu ); ++nleaf; }
+            if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
+            if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
+            if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
+            if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
         }
         for ( int i = 0; i < nleaf; ++i ) {
             uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
@@ -382,10 +393,10 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
             bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;
             if ( hit0 && hit1 ) {
                 bool zero_near = te0 <= te1;
-                T.stack[top * T.stride] = ( int ) ( zero_near ? child1 : child0 ); ++top;
-                T.stack[top * T.stride] = ( int ) ( zero_near ? child0 : child1 ); ++top;
-            } else if ( hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
-            else if ( hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
+                TERRA_PUSH ( T, top, ( zero_near ? child1 : child0 ) );
+                TERRA_PUSH ( T, top, ( zero_near ? child0 : child1 ) );
+            } else if ( hit0 ) { TERRA_PUSH ( T, top, child0 ); }
+            else if ( hit1 ) { TERRA_PUSH ( T, top, child1 ); }
         }
         if ( !leaf ) break;
         const uint32_t first = leaf & 0x07ffffffu, cnt = ( ( leaf >> 27 ) & 0xfu ) + 1;
@@ -439,10 +450,10 @@ TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 
                 bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
                 bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
                 bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
-                if ( !leaf0 && hit0 ) { T.stack[top * T.stride] = ( int ) child0; ++top; }
-                if ( !leaf1 && hit1 ) { T.stack[top * T.stride] = ( int ) child1; ++top; }
-                if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child0 & 0x7fffffffu ); ++nleaf; }
-                if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { T.leaves[nleaf * T.stride] = ( int ) ( child1 & 0x7fffffffu ); ++nleaf; }
+                if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
+                if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
+                if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
+                if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
             }
         }
         for ( int i = 0; i < nleaf; ++i ) {         // lanes that are not traversing hold nleaf == 0

@@ -42,6 +42,7 @@ def bits_equal(a, b):
     return np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
 
 
+faults_fn = lib.fn("terra_amd_debug_faults", C.c_longlong, [C.c_void_p]); faults = 0
 bad = 0
 for it in range(n_iter):
     n = int(rs.choice([2, 9, 40, 150, 400, 1200, 2500])); W, H = int(rs.randint(20, 70)), int(rs.randint(16, 50))
@@ -62,6 +63,7 @@ for it in range(n_iter):
         runtime.check(lib.render_device(C.byref(cam), s, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, None, None))
         torch.cuda.synchronize()
         outs.append((fb.results_host()["acc"].copy(), fb.pixels_host().copy()))
+        faults += max(0, faults_fn(s))
         lib.scene_destroy(s)
     ok0 = bits_equal(outs[0][0], fo.results["acc"]) and bits_equal(outs[0][1], fo.pixels)
     ok1 = bits_equal(outs[1][0], outs[0][0]) and bits_equal(outs[1][1], outs[0][1])
@@ -69,5 +71,5 @@ for it in range(n_iter):
         bad += 1; print("MISMATCH", dict(it=it, tris=n, W=W, H=H, integ=integ, split=split, spp=spp, bounces=d.bounces, tonemap=d.tonemap, env=d.environment_lighting, vs_oracle=ok0, fast_vs_ref=ok1,
                                          kinds=[o.material.kind for o in d.objects]))
     fo.destroy(); orc.scene_destroy(so); orc.scene_destroy(sc)
-print(f"{n_iter} cases, {bad} mismatches, last error: '{runtime.last_error()}'")
-sys.exit(1 if bad else 0)
+print(f"{n_iter} cases, {bad} mismatches, {faults} bounds faults, last error: '{runtime.last_error()}'")
+sys.exit(1 if bad or faults else 0)
