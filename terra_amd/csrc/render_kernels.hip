@@ -145,7 +145,16 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_WAVES_DECOUPLED
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
-#define TERRA_WAVES_FOR(I, K, M) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? TERRA_WAVES_LIGHT : ( TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) ) )
+#ifndef TERRA_WAVES_FAST_TREE      // fast-tree (MODE 2) kernels are latency bound: more resident waves pay for the extra scratch
+#define TERRA_WAVES_FAST_TREE 6     // (hall, 32 spp: 4 -> 81.2 ms, 5 -> 71.0 ms, 6 -> 67.2 ms; profiles/r01_measurements/ab_fw.log)
+#endif
+#ifndef TERRA_WAVES_FAST_TREE_LIGHT  // (hall, 16 spp, Direct / MIS: 4 -> 85.0 / 135.3 ms, 5 -> 79.3 / 122.2 ms, 6 -> 74.7 / 114.5 ms; ab_fl*.log)
+#define TERRA_WAVES_FAST_TREE_LIGHT 6
+#endif
+#ifndef TERRA_WAVES_GLOBAL_LIGHT     // reference tree read from global memory (MODE 0), Direct/MIS (sphere scene, Direct: 4 -> 864 ms, 5 -> 815 ms, 6 -> 841 ms; ab_gl*.log)
+#define TERRA_WAVES_GLOBAL_LIGHT 5
+#endif
+#define TERRA_WAVES_FOR(I, K, M) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? ( ( M ) == 2 ? TERRA_WAVES_FAST_TREE_LIGHT : ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : TERRA_WAVES_LIGHT ) : ( M ) == 2 ? TERRA_WAVES_FAST_TREE : ( TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) ) )
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
