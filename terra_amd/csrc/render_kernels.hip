@@ -154,7 +154,16 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_WAVES_GLOBAL_LIGHT     // reference tree read from global memory (MODE 0), Direct/MIS (sphere scene, Direct: 4 -> 864 ms, 5 -> 815 ms, 6 -> 841 ms; ab_gl*.log)
 #define TERRA_WAVES_GLOBAL_LIGHT 5
 #endif
-#define TERRA_WAVES_FOR(I, K, M) ( ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 ) ? ( ( M ) == 2 ? TERRA_WAVES_FAST_TREE_LIGHT : ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : TERRA_WAVES_LIGHT ) : ( M ) == 2 ? TERRA_WAVES_FAST_TREE : ( TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) ) )
+#ifndef TERRA_WAVES_FAST_TREE_GENERIC        // ... but the generic-kinds kernels (Phong/GGX/glass/textures compiled in) already spill at 5:
+#define TERRA_WAVES_FAST_TREE_GENERIC 5      // sphere scene, Simple, 64 spp: 5 -> 63.5 ms, 6 -> 70.1 ms, 7 -> 71.5 ms, 8 -> 81 ms (ab_ww2.log, ab_f78.log)
+#endif
+#ifndef TERRA_WAVES_FAST_TREE_GENERIC_LIGHT
+#define TERRA_WAVES_FAST_TREE_GENERIC_LIGHT 4
+#endif
+#define TERRA_IS_LIGHT(I) ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 )
+#define TERRA_WAVES_FOR(I, K, M) ( ( M ) == 2 ? ( ( K ) == 1 ? ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_LIGHT : TERRA_WAVES_FAST_TREE ) : ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_GENERIC_LIGHT : TERRA_WAVES_FAST_TREE_GENERIC ) ) \
+                                 : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : TERRA_WAVES_LIGHT ) \
+                                 : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
