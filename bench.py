@@ -63,6 +63,8 @@ def workload(name: str, spp_override):
         d = scenes.cornell_box(256, 256, 4, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "cornell_1080p_512spp_direct":
         d = scenes.cornell_box(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorDirect)
+    elif name == "cornell_phong_1080p_512spp":   # the Cornell box with Phong boxes (what OBJ/MTL scenes with Ks map to)
+        d = scenes.cornell_phong(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "hall_1080p_256spp":        # BASELINE.json configs[2]: ~100k triangles, deep reference-tree traversal
         d = scenes.sponza_hall(1920, 1080, 256, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "hall_2160p_4096spp":       # BASELINE.json configs[4]: the 100k scene at 3840x2160, 4096 spp (meant for 8 GPUs)

@@ -371,12 +371,19 @@ static hipError_t launch_kinds ( const DevRenderParams& p, uint32_t blocks, size
     else hipLaunchKernelGGL ( ( terra_render_kernel<I, 2, MODE, KINDS> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
     return hipGetLastError();
 }
+// kinds present in the scene -> the leanest compiled variant that covers them: diffuse only (1), diffuse + Phong (3: what
+// OBJ/MTL scenes map to, satellite/src/Scene.cpp:193-230), or everything (GGX, glass, textures, environment term)
+template <int I, int MODE>
+static hipError_t launch_mode ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
+    if ( p.bsdf_kinds == 1 ) return launch_kinds<I, MODE, 1> ( p, blocks, lds, stream );
+    if ( ( p.bsdf_kinds & ~3u ) == 0 ) return launch_kinds<I, MODE, 3> ( p, blocks, lds, stream );
+    return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
+}
 template <int I>
 static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
-    const bool diffuse_only = p.bsdf_kinds == 1;
-    if ( p.lds_mode == 1 ) return diffuse_only ? launch_kinds<I, 1, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 1, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
-    if ( p.lds_mode == 2 ) return diffuse_only ? launch_kinds<I, 2, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 2, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
-    return diffuse_only ? launch_kinds<I, 0, 1> ( p, blocks, lds, stream ) : launch_kinds<I, 0, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
+    if ( p.lds_mode == 1 ) return launch_mode<I, 1> ( p, blocks, lds, stream );
+    if ( p.lds_mode == 2 ) return launch_mode<I, 2> ( p, blocks, lds, stream );
+    return launch_mode<I, 0> ( p, blocks, lds, stream );
 }
 
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {
