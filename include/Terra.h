@@ -44,168 +44,150 @@ extern "C" {
 #endif
 
 /* ---- shading ------------------------------------------------------------ */
+/* Byte offsets (x86-64 SysV) are written next to the fields; the TERRA_ABI_ASSERT block at the end of the file
+   checks them. Enumerators carry their values explicitly: they travel through the ABI as plain ints. */
 
-/* Per-hit shading frame handed to the BSDF routines (188 bytes). */
-typedef struct {
-    TerraFloat4x4 transform;   /* columns: tangent, normal, bitangent */
-    TerraFloat3   normal;
-    TerraFloat3   emissive;
-    float         ior;
-    TerraFloat3   attributes[TERRA_MATERIAL_MAX_ATTRIBUTES];
+/* Per-hit shading frame handed to the BSDF routines. 188 bytes. */
+typedef struct TerraShadingSurface_s {
+    TerraFloat4x4 transform;                                    /* +0    columns: tangent, normal, bitangent */
+    TerraFloat3   normal;                                       /* +64   interpolated, normalised, not face-forwarded */
+    TerraFloat3   emissive;                                     /* +76   */
+    float         ior;                                          /* +88   */
+    TerraFloat3   attributes[TERRA_MATERIAL_MAX_ATTRIBUTES];    /* +92   evaluated material attributes; presets also use slots as scratch */
 } TerraShadingSurface;
 
-typedef TerraFloat3 ( TerraBSDFSampleRoutine ) ( const TerraShadingSurface* surface, float e1, float e2, float e3, const TerraFloat3* wo );
-typedef float       ( TerraBSDFPdfRoutine )    ( const TerraShadingSurface* surface, const TerraFloat3* wi, const TerraFloat3* wo );
-typedef TerraFloat3 ( TerraBSDFEvalRoutine )   ( const TerraShadingSurface* surface, const TerraFloat3* wi, const TerraFloat3* wo );
+/* sample(surface, e1, e2, e3, wo) -> wi;  pdf(surface, wi, wo);  eval(surface, wi, wo) -> f */
+typedef TerraFloat3 ( TerraBSDFSampleRoutine ) ( const TerraShadingSurface* surface, float e1, float e2, float e3,
+                                                 const TerraFloat3* wo );
+typedef float       ( TerraBSDFPdfRoutine ) ( const TerraShadingSurface* surface, const TerraFloat3* wi,
+                                              const TerraFloat3* wo );
+typedef TerraFloat3 ( TerraBSDFEvalRoutine ) ( const TerraShadingSurface* surface, const TerraFloat3* wi,
+                                               const TerraFloat3* wo );
 
-/* A BSDF is three routines. On the device only the library's own presets
+/* A BSDF is three routines (24 bytes). On the device only the library's own presets
    (TerraPresets.h) are executable; they are recognised by pointer identity. */
-typedef struct {
-    TerraBSDFSampleRoutine* sample;
-    TerraBSDFPdfRoutine*    pdf;
-    TerraBSDFEvalRoutine*   eval;
+typedef struct TerraBSDF_s {
+    TerraBSDFSampleRoutine* sample;     /* +0  */
+    TerraBSDFPdfRoutine*    pdf;        /* +8  */
+    TerraBSDFEvalRoutine*   eval;       /* +16 */
 } TerraBSDF;
 
-typedef enum {
-    kTerraFilterPoint,
-    kTerraFilterBilinear,
-    kTerraFilterTrilinear,
-    kTerraFilterAnisotropic
-} TerraFilter;
+typedef enum { kTerraFilterPoint = 0, kTerraFilterBilinear = 1, kTerraFilterTrilinear = 2, kTerraFilterAnisotropic = 3 } TerraFilter;
 
-typedef enum {
-    kTerraTextureAddressWrap,
-    kTerraTextureAddressMirror,
-    kTerraTextureAddressClamp
-} TerraTextureAddressMode;
+typedef enum { kTerraTextureAddressWrap = 0, kTerraTextureAddressMirror = 1, kTerraTextureAddressClamp = 2 } TerraTextureAddressMode;
 
-/* pixels == NULL marks an invalid texture */
-typedef struct {
-    void*    pixels;
-    uint16_t width;
-    uint16_t height;
-    uint8_t  components;
-    uint8_t  depth;          /* bytes per component: 1 (unorm8) or 4 (float) */
-    uint8_t  filter;         /* TerraFilter */
-    uint8_t  address_mode;   /* TerraTextureAddressMode */
+/* 16 bytes; pixels == NULL marks an invalid texture */
+typedef struct TerraTexture_s {
+    void*    pixels;         /* +0   width * height * components elements, owned by the texture */
+    uint16_t width;          /* +8   */
+    uint16_t height;         /* +10  */
+    uint8_t  components;     /* +12  */
+    uint8_t  depth;          /* +13  bytes per component: 1 (unorm8) or 4 (float) */
+    uint8_t  filter;         /* +14  TerraFilter */
+    uint8_t  address_mode;   /* +15  TerraTextureAddressMode */
 } TerraTexture;
 
-typedef void        ( *TerraAttributeFinalize ) ( void* attribute );
-typedef TerraFloat3 ( *TerraAttributeEval )     ( void* attribute, const void* texcoord, const void* world_pos );
+typedef void        ( *TerraAttributeFinalize ) ( void* state );
+typedef TerraFloat3 ( *TerraAttributeEval ) ( void* state, const void* texcoord_or_direction, const void* world_position );
 
-/* state == NULL: constant `value`; otherwise eval(state, uv, xyz) */
-typedef struct {
-    void*                  state;
-    TerraAttributeFinalize finalize;
-    TerraAttributeEval     eval;
-    TerraFloat3            value;
+/* 40 bytes. state == NULL: the constant `value`; otherwise eval(state, uv, xyz) */
+typedef struct TerraAttribute_s {
+    void*                  state;       /* +0   borrowed (a TerraTexture*) */
+    TerraAttributeFinalize finalize;    /* +8   */
+    TerraAttributeEval     eval;        /* +16  */
+    TerraFloat3            value;       /* +24  */
 } TerraAttribute;
 
-typedef struct {
-    TerraBSDF      bsdf;
-    float          ior;
-    TerraAttribute emissive;
-    TerraAttribute attributes[TERRA_MATERIAL_MAX_ATTRIBUTES];
-    size_t         attributes_count;
-    bool           enable_bump_map_attr;
-    bool           enable_normal_map_attr;
+/* 408 bytes */
+typedef struct TerraMaterial_s {
+    TerraBSDF      bsdf;                                        /* +0   */
+    float          ior;                                         /* +24  */
+    TerraAttribute emissive;                                    /* +32  */
+    TerraAttribute attributes[TERRA_MATERIAL_MAX_ATTRIBUTES];   /* +72  slots named by the preset (TerraPresets.h) */
+    size_t         attributes_count;                            /* +392 */
+    bool           enable_bump_map_attr;                        /* +400 unused by the renderer */
+    bool           enable_normal_map_attr;                      /* +401 unused by the renderer */
 } TerraMaterial;
 
 /* ---- geometry ----------------------------------------------------------- */
 
 typedef struct TerraAABB {
-    TerraFloat3 min;
-    TerraFloat3 max;
+    TerraFloat3 min;    /* +0  */
+    TerraFloat3 max;    /* +12 */
 } TerraAABB;
 
-typedef struct {
-    TerraFloat3 a, b, c;
-} TerraTriangle;
+typedef struct TerraTriangle_s { TerraFloat3 a, b, c; } TerraTriangle;                          /* 36 bytes */
 
-typedef struct {
-    TerraFloat3 normal_a, normal_b, normal_c;
-    TerraFloat2 texcoord_a, texcoord_b, texcoord_c;
+typedef struct TerraTriangleProperties_s {                                                      /* 60 bytes */
+    TerraFloat3 normal_a, normal_b, normal_c;           /* +0  per-vertex normals */
+    TerraFloat2 texcoord_a, texcoord_b, texcoord_c;     /* +36 per-vertex texture coordinates, in TEXELS */
 } TerraTriangleProperties;
 
-/* Returned by terra_scene_add_object(); the caller fills triangles[],
+/* 432 bytes. Returned by terra_scene_add_object(); the caller fills triangles[],
    properties[] and material in place before terra_scene_commit(). */
-typedef struct {
-    TerraTriangle*           triangles;
-    TerraTriangleProperties* properties;
-    size_t                   triangles_count;
-    TerraMaterial            material;
+typedef struct TerraObject_s {
+    TerraTriangle*           triangles;         /* +0   triangles_count elements, owned by the scene */
+    TerraTriangleProperties* properties;        /* +8   triangles_count elements, owned by the scene */
+    size_t                   triangles_count;   /* +16  */
+    TerraMaterial            material;          /* +24  */
 } TerraObject;
 
 /* ---- options ------------------------------------------------------------ */
 
 typedef enum {
-    kTerraTonemappingOperatorNone,
-    kTerraTonemappingOperatorLinear,
-    kTerraTonemappingOperatorReinhard,
-    kTerraTonemappingOperatorFilmic,
-    kTerraTonemappingOperatorUncharted2
+    kTerraTonemappingOperatorNone = 0, kTerraTonemappingOperatorLinear = 1, kTerraTonemappingOperatorReinhard = 2,
+    kTerraTonemappingOperatorFilmic = 3, kTerraTonemappingOperatorUncharted2 = 4
 } TerraTonemappingOperator;
 
-typedef enum {
-    kTerraAcceleratorBVH
-} TerraAccelerator;
+typedef enum { kTerraAcceleratorBVH = 0 } TerraAccelerator;
+
+typedef enum { kTerraSamplingMethodRandom = 0, kTerraSamplingMethodStratified = 1, kTerraSamplingMethodHalton = 2 } TerraSamplingMethod;
 
 typedef enum {
-    kTerraSamplingMethodRandom,
-    kTerraSamplingMethodStratified,
-    kTerraSamplingMethodHalton
-} TerraSamplingMethod;
-
-typedef enum {
-    kTerraIntegratorSimple,
-    kTerraIntegratorDirect,
-    kTerraIntegratorDirectMis,
-    kTerraIntegratorDebugMono,
-    kTerraIntegratorDebugDepth,
-    kTerraIntegratorDebugNormals,
-    kTerraIntegratorDebugMisWeights,
+    kTerraIntegratorSimple = 0, kTerraIntegratorDirect = 1, kTerraIntegratorDirectMis = 2, kTerraIntegratorDebugMono = 3,
+    kTerraIntegratorDebugDepth = 4, kTerraIntegratorDebugNormals = 5, kTerraIntegratorDebugMisWeights = 6
 } TerraIntegrator;
 
-/* Edited through terra_scene_get_options(); takes effect at the next
+/* 96 bytes. Edited through terra_scene_get_options(); takes effect at the next
    terra_scene_commit(). */
-typedef struct {
-    TerraAttribute           environment_map;
-    TerraTonemappingOperator tonemapping_operator;
-    TerraAccelerator         accelerator;
-    TerraSamplingMethod      sampling_method;
-    TerraIntegrator          integrator;
-
-    float  subpixel_jitter;
-    size_t samples_per_pixel;
-    size_t bounces;
-    size_t strata;
-
-    float  manual_exposure;
-    float  gamma;
+typedef struct TerraSceneOptions_s {
+    TerraAttribute           environment_map;           /* +0   see terra_amd_set_environment_lighting (terra_amd.h) */
+    TerraTonemappingOperator tonemapping_operator;      /* +40  */
+    TerraAccelerator         accelerator;               /* +44  */
+    TerraSamplingMethod      sampling_method;           /* +48  only the stratified spp round-up has an effect, as in the reference */
+    TerraIntegrator          integrator;                /* +52  */
+    float                    subpixel_jitter;           /* +56  */
+    size_t                   samples_per_pixel;         /* +64  */
+    size_t                   bounces;                   /* +72  */
+    size_t                   strata;                    /* +80  */
+    float                    manual_exposure;           /* +88  */
+    float                    gamma;                     /* +92  */
 } TerraSceneOptions;
 
-typedef struct {
-    TerraFloat3 position;
-    TerraFloat3 direction;
-    TerraFloat3 up;
-    float       fov;          /* vertical, degrees */
+/* 40 bytes; left-handed: x right, y up, z forward */
+typedef struct TerraCamera_s {
+    TerraFloat3 position;     /* +0  */
+    TerraFloat3 direction;    /* +12 */
+    TerraFloat3 up;           /* +24 */
+    float       fov;          /* +36 vertical, degrees */
 } TerraCamera;
 
-/* Running sum of radiance and the number of samples in it, per pixel. */
-typedef struct {
-    TerraFloat3 acc;
-    int         samples;
+/* 16 bytes: running sum of radiance and the number of samples in it, per pixel. */
+typedef struct TerraRawIntegrationResult_s {
+    TerraFloat3 acc;        /* +0  */
+    int         samples;    /* +12 */
 } TerraRawIntegrationResult;
 
-/* Host framebuffer, row-major, index = y * width + x. */
-typedef struct {
-    TerraFloat3*               pixels;    /* tonemapped running mean */
-    TerraRawIntegrationResult* results;
-    size_t                     width;
-    size_t                     height;
+/* 32 bytes: host framebuffer, row-major, index = y * width + x. */
+typedef struct TerraFramebuffer_s {
+    TerraFloat3*               pixels;    /* +0  tonemapped running mean */
+    TerraRawIntegrationResult* results;   /* +8  */
+    size_t                     width;     /* +16 */
+    size_t                     height;    /* +24 */
 } TerraFramebuffer;
 
-typedef struct {
+/* 4 bytes: what a leaf of the reference's tree stores (8 bits of object index: at most 256 objects) */
+typedef struct TerraPrimitiveRef_s {
     uint32_t object_idx   : 8;
     uint32_t triangle_idx : 24;
 } TerraPrimitiveRef;
