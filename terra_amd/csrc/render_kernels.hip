@@ -142,6 +142,11 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #define TERRA_DECOUPLED_LDS 0
 #endif
 #define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
+// ... and Direct, whose one shadow ray per hit becomes a traversal job of its own (scenes without textured attributes)
+#ifndef TERRA_DECOUPLED_DIRECT_ENABLE
+#define TERRA_DECOUPLED_DIRECT_ENABLE 1
+#endif
+#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( M ) == 0 && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_WAVES_DECOUPLED
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
@@ -191,7 +196,92 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     uint32_t s = 0, bounce = 0;
     const V3 cam_pos = v3p ( p.cam_pos );
 
-    if constexpr ( TERRA_DECOUPLED ( INTEGRATOR, MODE ) ) {
+    if constexpr ( TERRA_DECOUPLED_DIRECT ( INTEGRATOR, MODE, KINDS ) ) {
+        // Decoupled loop for the Direct integrator. A lane's ray in flight is either a path segment (MAIN) or the shadow
+        // ray of the hit it just shaded (SHADOW). Shading a MAIN hit draws the light sample, prepares both outcomes of the
+        // shadow test (direct_prepare), samples the BSDF and plays Russian roulette -- all stream draws in the reference's
+        // order -- parks the continuation ray and sends the shadow ray; when that returns, the matching outcome is added
+        // and the continuation (or the pixel's next sample) starts. Same rays, same draws, same sums as integrate_direct.
+        RayState st = ray_state_init ( ray );
+        Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
+        int top = 0, nleaf = 0;
+        bool traversing = false, done = !valid, have_ray = false, regular = true, shadow = false, cont = false;
+        DirectPending pend; pend.vis = pend.hid = v3 ( 0, 0, 0 ); pend.expected = 0;
+        V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 );
+        for ( ;; ) {
+            if ( !traversing && !done ) {
+                bool start = false;
+                if ( have_ray && shadow ) {                      // the shadow ray came back
+                    if ( best.tri != 0xffffffffu ) {             // (its hit counts as a surface init, as in the coupled form)
+                        if ( COUNT ) ++c.hits;
+                        if ( COUNT == 2 ) { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * best.tri]; c.attr_fetches += T.sc.mats[__float_as_uint ( t0.w )].attributes_count + 1; }
+                    }
+                    Lo = Lo + ( best.tri == pend.expected ? pend.vis : pend.hid );
+                    shadow = false;
+                    if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
+                    else { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false; }
+                } else if ( have_ray ) {                         // a path segment came back
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;
+                    if ( best.tri != 0xffffffffu ) {
+                        Surface sf;
+                        V3 point = r.o + r.d * best.depth;
+                        uint32_t object, tri_in_object, nattr;
+                        surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+                        if ( COUNT ) ++c.hits;
+                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+                        V3 wo = neg ( ray.d );
+                        Ray shadow_ray;
+                        pend = direct_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
+                        float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
+                        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+                        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
+                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
+                        throughput = had ( throughput, f );
+                        throughput = throughput * dot ( sf.normal, wi );
+                        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
+                        float e3 = randf ( rs.b, c, COUNT );
+                        cont = false;
+                        if ( ! ( e3 > pr ) ) {
+                            throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+                            V3 off = sf.normal * 0.0001f;       // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are redone when the ray starts
+                            cont_o = point + off; cont_d = wi;
+                            ++bounce;
+                            cont = bounce <= p.bounces;
+                        }
+                        ray = shadow_ray; shadow = true; start = true;
+                    } else {
+                        if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
+                        acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false;
+                    }
+                }
+                if ( !start ) {                                  // the path ended (or none was started yet): the pixel's next sample
+                    if ( s == p.chunk_spp ) done = true;
+                    else {
+                        float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
+                        ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
+                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; start = true;
+                    }
+                }
+                if ( start ) {
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;
+                    st = ray_state_init ( r );
+                    regular = ray_is_regular ( r );
+                    best.depth = FLT_MAX; best.tri = 0xffffffffu;
+                    T.stack[0] = 0; top = 1; nleaf = 0;
+                    traversing = true; have_ray = true;
+                    if ( COUNT ) ++c.rays;
+                }
+            }
+            const int n_trav = __popcll ( __ballot ( traversing ) );
+            if ( n_trav == 0 ) break;
+            int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+            const int exit_active = n_trav - quota;
+            Ray r = ray; r.o = r.o + r.d * 0.001f;
+            V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+            if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+        }
+    } else if constexpr ( TERRA_DECOUPLED ( INTEGRATOR, MODE ) ) {
         // Decoupled loop (scenes read from global memory, integrators without nested raycasts): a lane is either
         // traversing its current ray or waiting to be shaded. The resumable traversal returns as soon as a quarter of
         // the lanes that entered it have finished; those are shaded and handed their next ray (continuation or the

@@ -839,6 +839,33 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
     return had ( Lo, throughput );
 }
 
+// integrate_direct split at its shadow ray, for the decoupled loop (render_kernels.hip): everything that does not depend
+// on the shadow ray's outcome is done up front -- same operations in the same order -- and both possible return values
+// are kept: `hid` (light sample not visible) and `vis` (visible). Valid for scenes without textured attributes, where the
+// emissive the shadow ray's surface_init would read is the light material's constant.
+struct DirectPending { V3 vis, hid; uint32_t expected; };
+template <int COUNT, int KINDS>
+TD DirectPending direct_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c, Ray& shadow_ray ) {
+    const DevScene& sc = T.sc;
+    V3 Lo = v3 ( 0, 0, 0 );
+    if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
+    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    V3 p_to_light = ls.pos - p;
+    V3 wi = normalize ( p_to_light );
+    shadow_ray = surface_ray ( sf, p, wi, 1.f );
+    DirectPending d;
+    d.hid = had ( Lo, throughput ); d.vis = d.hid; d.expected = ls.tri;
+    float cosv = dot ( neg ( wi ), ls.norm );
+    if ( cosv > 0 ) {
+        V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
+        float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[ls.tri] );
+        V3 Ld = had ( v3p ( sc.mats[ls.light_object].emissive ), f );
+        Ld = Ld * ( dot ( wi, sf.normal ) / ( pdf * ls.pick_pdf ) );
+        d.vis = had ( Lo + Ld, throughput );
+    }
+    return d;
+}
+
 template <int COUNT, int MODE, int KINDS, bool DEBUG_WEIGHTS>
 TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     const DevScene& sc = T.sc;

@@ -339,7 +339,7 @@ def test_fast_tree_hall_goldens_and_work(H, L):
 # the work counters behind Mrays/s and the roofline's algorithmic bytes
 # ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name,integ", [("cornell", 0), ("cornell", 1), ("phong", 2), ("hall", 0)])
+@pytest.mark.parametrize("name,integ", [("cornell", 0), ("cornell", 1), ("phong", 2), ("hall", 0), ("hall", 1), ("hall", 2)])
 def test_device_work_counters_equal_the_oracles(H, L, orc_lib, devmath_mode, name, integ):
     import ctypes as C
     d = {"cornell": scenes.cornell_box, "phong": scenes.cornell_phong}.get(name, None)
@@ -505,7 +505,7 @@ def test_automatic_tree_mode_picks_by_scene_size(H, L):
 # different rays; per pixel nothing may change
 # ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name,integ", [("spheres", 0), ("spheres", 4), ("spheres", 5), ("soup", 0), ("soup", 3), ("hall", 4)])
+@pytest.mark.parametrize("name,integ", [("spheres", 0), ("spheres", 4), ("spheres", 5), ("soup", 0), ("soup", 3), ("hall", 4), ("soup", 1), ("hall", 1)])
 def test_decoupled_loop_matches_the_oracle(H, L, orc_lib, devmath_mode, name, integ):
     if name == "spheres":       # GGX + glass + diffuse: the generic kinds, 3,980 triangles, ragged frame, environment term on
         d = scenes.cornell_spheres(104, 72, 3, integrator=integ, environment=(0.3, 0.4, 0.9), environment_lighting=True)
