@@ -147,6 +147,10 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #define TERRA_DECOUPLED_DIRECT_ENABLE 1
 #endif
 #define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( M ) == 0 && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#ifndef TERRA_DECOUPLED_MIS_ENABLE
+#define TERRA_DECOUPLED_MIS_ENABLE 1
+#endif
+#define TERRA_DECOUPLED_MIS(I, M, K) ( TERRA_DECOUPLED_MIS_ENABLE && ( M ) == 0 && ( I ) == 2 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_WAVES_DECOUPLED
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
@@ -196,7 +200,100 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     uint32_t s = 0, bounce = 0;
     const V3 cam_pos = v3p ( p.cam_pos );
 
-    if constexpr ( TERRA_DECOUPLED_DIRECT ( INTEGRATOR, MODE, KINDS ) ) {
+    if constexpr ( TERRA_DECOUPLED_MIS ( INTEGRATOR, MODE, KINDS ) ) {
+        // Decoupled loop for Direct + MIS: like the Direct one below with two shadow jobs per shaded hit, in the reference's
+        // order -- A: the ray to the light sample, B: the BSDF-sampled ray (mis_prepare / mis_finish_b).
+        RayState st = ray_state_init ( ray );
+        Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
+        int top = 0, nleaf = 0, job = 0;                         // job: 0 path segment, 1 shadow ray A, 2 shadow ray B
+        bool traversing = false, done = !valid, have_ray = false, regular = true, cont = false;
+        MisPending pend; pend.a_vis = pend.a_hid = pend.f2 = pend.p = pend.t_before = v3 ( 0, 0, 0 ); pend.expected = 0; pend.bpdf2 = pend.cos2 = 0.f; pend.light_object = 0;
+        V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 ), b_o = v3 ( 0, 0, 0 ), b_d = v3 ( 0, 0, 1 ), lo_i = v3 ( 0, 0, 0 );
+        for ( ;; ) {
+            if ( !traversing && !done ) {
+                bool start = false;
+                if ( have_ray && job != 0 ) {
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;
+                    const bool hit = best.tri != 0xffffffffu;
+                    Surface lsf; uint32_t object = 0, tri_in_object = 0, nattr = 0;
+                    V3 point = hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
+                    if ( hit ) {
+                        if ( job == 2 ) surface_init<MODE, KINDS> ( T, best.tri, point, lsf, object, tri_in_object, nattr );
+                        else { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * best.tri]; object = __float_as_uint ( t0.w ); nattr = T.sc.mats[object].attributes_count; }
+                        if ( COUNT ) ++c.hits;
+                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+                    }
+                    if ( job == 1 ) {                            // A came back: pick its outcome, send B
+                        lo_i = best.tri == pend.expected ? pend.a_vis : pend.a_hid;
+                        ray = make_ray ( b_o, b_d ); job = 2; start = true;
+                    } else {                                     // B came back: the integrator's value is complete
+                        Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, best.tri, point, lsf, ray.d );
+                        job = 0;
+                        if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
+                        else { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false; }
+                    }
+                } else if ( have_ray ) {                         // a path segment came back
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;
+                    if ( best.tri != 0xffffffffu ) {
+                        Surface sf;
+                        V3 point = r.o + r.d * best.depth;
+                        uint32_t object, tri_in_object, nattr;
+                        surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+                        if ( COUNT ) ++c.hits;
+                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+                        V3 wo = neg ( ray.d );
+                        Ray ray_a;
+                        pend = mis_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
+                        b_o = point + sf.normal * 0.0001f;        // surface_ray ( sf, point, bsdf_dir, 1.f ) without the divisions
+                        float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
+                        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+                        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
+                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
+                        throughput = had ( throughput, f );
+                        throughput = throughput * dot ( sf.normal, wi );
+                        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
+                        float e3 = randf ( rs.b, c, COUNT );
+                        cont = false;
+                        if ( ! ( e3 > pr ) ) {
+                            throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+                            cont_o = point + sf.normal * 0.0001f; cont_d = wi;
+                            ++bounce;
+                            cont = bounce <= p.bounces;
+                        }
+                        ray = ray_a; job = 1; start = true;
+                    } else {
+                        if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
+                        acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false;
+                    }
+                }
+                if ( !start ) {
+                    if ( s == p.chunk_spp ) done = true;
+                    else {
+                        float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
+                        ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
+                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; job = 0; start = true;
+                    }
+                }
+                if ( start ) {
+                    Ray r = ray; r.o = r.o + r.d * 0.001f;
+                    st = ray_state_init ( r );
+                    regular = ray_is_regular ( r );
+                    best.depth = FLT_MAX; best.tri = 0xffffffffu;
+                    T.stack[0] = 0; top = 1; nleaf = 0;
+                    traversing = true; have_ray = true;
+                    if ( COUNT ) ++c.rays;
+                }
+            }
+            const int n_trav = __popcll ( __ballot ( traversing ) );
+            if ( n_trav == 0 ) break;
+            int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+            const int exit_active = n_trav - quota;
+            Ray r = ray; r.o = r.o + r.d * 0.001f;
+            V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+            if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+        }
+    } else if constexpr ( TERRA_DECOUPLED_DIRECT ( INTEGRATOR, MODE, KINDS ) ) {
         // Decoupled loop for the Direct integrator. A lane's ray in flight is either a path segment (MAIN) or the shadow
         // ray of the hit it just shaded (SHADOW). Shading a MAIN hit draws the light sample, prepares both outcomes of the
         // shadow test (direct_prepare), samples the BSDF and plays Russian roulette -- all stream draws in the reference's

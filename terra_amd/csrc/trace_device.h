@@ -866,6 +866,68 @@ TD DirectPending direct_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 
     return d;
 }
 
+// integrate_mis (DEBUG_WEIGHTS = false) split at its two rays, for the decoupled loop. mis_prepare does everything that
+// precedes the light-sample shadow ray (job A) and prepares both of its outcomes as the integrator's running sum
+// (a_hid: emissive term only; a_vis: + the light-sample term); it also evaluates what the BSDF-sample ray (job B) will
+// need from the shaded surface. mis_finish_b applies job B's hit to the running sum exactly as integrate_mis does.
+// Job A's visible term uses the light material's constant emissive: valid for scenes without textured attributes.
+struct MisPending { V3 a_vis, a_hid; uint32_t expected; V3 f2; float bpdf2, cos2; V3 p; uint32_t light_object; V3 t_before; };
+template <int COUNT, int KINDS>
+TD MisPending mis_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c, Ray& ray_a, V3& dir_b ) {
+    const DevScene& sc = T.sc;
+    V3 Lo = v3 ( 0, 0, 0 );
+    if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
+    float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT ), e3 = randf ( rb, c, COUNT );
+    V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo );
+    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    MisPending m;
+    m.a_hid = Lo; m.a_vis = Lo; m.expected = ls.tri; m.p = p; m.light_object = ls.light_object; m.t_before = throughput;
+    {
+        V3 p_to_light = ls.pos - p;
+        V3 wi = normalize ( p_to_light );
+        ray_a = surface_ray ( sf, p, wi, 1.f );
+        float cosv = dot ( ls.norm, neg ( wi ) );
+        if ( cosv > 0 ) {
+            float bpdf = bsdf_pdf<KINDS> ( sf, wi, wo );
+            float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[ls.tri] );
+            float weight = ( lpdf * lpdf ) / ( lpdf * lpdf + bpdf * bpdf );
+            if ( lpdf != 0 ) {
+                V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
+                V3 L = had ( v3p ( sc.mats[ls.light_object].emissive ), f );
+                L = L * ( dot ( wi, sf.normal ) * weight / ( lpdf * ls.pick_pdf ) );
+                m.a_vis = Lo + L;
+            }
+        }
+    }
+    dir_b = bsdf_dir;
+    m.f2 = bsdf_eval<KINDS> ( sf, bsdf_dir, wo );
+    m.bpdf2 = bsdf_pdf<KINDS> ( sf, bsdf_dir, wo );
+    m.cos2 = dot ( bsdf_dir, sf.normal );
+    return m;
+}
+// job B came back with closest hit (tri, point, shaded surface lsf of the hit): returns the integrator's value
+template <int MODE>
+TD V3 mis_finish_b ( const Tracer& T, const MisPending& m, V3 Lo, bool hit, uint32_t hit_object, uint32_t hit_tri, V3 hit_point, const Surface& lsf, V3 wi ) {
+    if ( hit && hit_object == m.light_object ) {
+        float NoW = dot ( lsf.normal, neg ( wi ) );
+        if ( NoW > 0 ) {
+            V3 dl = m.p - hit_point;
+            float dist = dot ( dl, dl );
+            const float4* tris = reinterpret_cast<const float4*> ( T.sc.tris );
+            float4 t0 = tris[3 * hit_tri + 0], t1 = tris[3 * hit_tri + 1], t2 = tris[3 * hit_tri + 2];
+            float area = triangle_area ( v3 ( t0.x, t0.y, t0.z ), v3 ( t1.x, t1.y, t1.z ), v3 ( t2.x, t2.y, t2.z ) );
+            float lpdf = dist / ( NoW * area );
+            float weight = ( m.bpdf2 * m.bpdf2 ) / ( lpdf * lpdf + m.bpdf2 * m.bpdf2 );
+            if ( m.bpdf2 != 0 ) {
+                V3 L = had ( lsf.emissive, m.f2 );
+                L = L * ( m.cos2 * weight / m.bpdf2 );
+                Lo = Lo + L;
+            }
+        }
+    }
+    return had ( Lo, m.t_before );
+}
+
 template <int COUNT, int MODE, int KINDS, bool DEBUG_WEIGHTS>
 TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     const DevScene& sc = T.sc;
