@@ -257,8 +257,8 @@ def main():
         traffic = None
         tf = ROOT / "profiles" / "roofline_traffic.json"
         if tf.exists() and world == 1 and not args.spp:
-            rec = json.loads(tf.read_text()).get(args.workload, {})
-            if rec.get("sample_split", 1) == args.sample_split and args.tree == "reference":      # the PMC passes were taken on this configuration
+            rec = json.loads(tf.read_text()).get(args.workload + ("" if args.tree == "reference" else ":" + args.tree), {})
+            if rec.get("sample_split", 1) == args.sample_split and not args.integrator:      # the PMC passes were taken on this configuration
                 traffic = rec.get("hbm_bytes_per_launch")
         out = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
