@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 from terra_amd import api, runtime, scenes
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+SCALE = float(os.environ.get("FUZZ_SCALE", "1"))       # multiplies every coordinate (scene and camera): the 1e-4 box margins do not scale with it
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = runtime.load()
 orc = api.TerraLib(os.path.join(ROOT, "oracle", "liboracle.so"), "orc_")
@@ -25,7 +26,7 @@ def soup(n_tris, n_objects):
         n = per if k < n_objects - 1 else left
         if n <= 0: break
         left -= n
-        c = rs.uniform(-2, 2, size=(n, 1, 3)); tris = (c + rs.uniform(-0.5, 0.5, size=(n, 3, 3))).astype(np.float32)
+        c = rs.uniform(-2, 2, size=(n, 1, 3)); tris = ((c + rs.uniform(-0.5, 0.5, size=(n, 3, 3))) * SCALE).astype(np.float32)
         e1 = tris[:, 1] - tris[:, 0]; e2 = tris[:, 2] - tris[:, 0]
         nrm = np.cross(e1, e2); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
         nrm = np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)
@@ -48,7 +49,7 @@ for it in range(n_iter):
     n = int(rs.choice([2, 9, 40, 150, 400, 1200, 2500])); W, H = int(rs.randint(20, 70)), int(rs.randint(16, 50))
     integ = int(rs.randint(0, 7)); split = int(rs.choice([1, 1, 2, 4])); spp = split * int(rs.randint(1, 3))
     d = scenes.SceneDesc(objects=soup(n, int(rs.randint(1, 5))), width=W, height=H, spp=spp, bounces=int(rs.randint(0, 6)), integrator=integ,
-                         camera_position=(0.0, 0.0, -6.0), tonemap=int(rs.randint(0, 5)), environment=(0.2, 0.3, 0.4), environment_lighting=bool(rs.randint(2)),
+                         camera_position=(0.0, 0.0, -6.0 * SCALE), tonemap=int(rs.randint(0, 5)), environment=(0.2, 0.3, 0.4), environment_lighting=bool(rs.randint(2)),
                          jitter=float(rs.choice([0.0, 0.5])))      # jitter 0 on odd frame sizes gives rays with exactly zero direction components (the exact slab path)
     cam = scenes.camera_of(d)
     so = scenes.build_scene(orc, d); fo = api.Framebuffer(orc, W, H)
