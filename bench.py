@@ -17,6 +17,9 @@ dealt round-robin to the ranks (t % N == rank), each rank renders its tiles on
 its own scene replica, and ONE gather (RCCL over xGMI) moves the packed tiles to
 rank 0, which unpacks them into the full frame. Total work is fixed as N grows:
 "scaling": "strong". value = frame samples * K / max-over-ranks wall time.
+Every rank count renders with the same sample split (terra_amd_set_sample_split, default 8 lanes per pixel:
+the frame of 8 successive 64-spp calls), so the image does not depend on N and a 1/8 share of the frame
+still fills a GPU.
 
 Also on the JSON line (rank 0):
   roofline     -- the render kernel's ALGORITHMIC bytes per launch (device work
