@@ -16,6 +16,7 @@
 // not the padded ones (DESIGN.md "Roofline").
 #pragma once
 #include <stdint.h>
+#include <hip/hip_vector_types.h>     // float4 (DevRenderParams::partials)
 
 #define TERRA_DEV_MAX_ATTR 8
 

@@ -26,6 +26,7 @@
 #include "../../include/TerraPresets.h"
 #include "dev_types.h"
 #include "kernels.h"
+#include "tree_build.h"
 
 // ------------------------------------------------------------------------------
 // error channel
@@ -217,9 +218,6 @@ extern "C" void terra_framebuffer_destroy ( TerraFramebuffer* fb ) {
 // ------------------------------------------------------------------------------
 // scene
 // ------------------------------------------------------------------------------
-struct HostNode { TerraAABB aabb[2]; int32_t index[2]; int32_t type[2]; };   // reference node layout (src/TerraBVH.h:13-17)
-static_assert ( sizeof ( HostNode ) == 64, "reference node is 64 bytes" );
-
 struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 
 struct Scene {
@@ -319,222 +317,6 @@ extern "C" void terra_scene_destroy ( HTerraScene h ) {
     delete s;
 }
 
-// ---- BVH build: the reference's tree ------------------------
-// Per-triangle boxes inflated by 1e-4 (double add, rounded), one stable sort by
-// DESCENDING box-centre x (what the reference's bool comparator produces under
-// glibc's merge sort), sweep SAH per range with the first minimum winning, inner
-// boxes growing their max by 1e-4 per merge, children numbered left-then-right when
-// the parent is expanded and the right range expanded first (LIFO task stack).
-namespace bvh {
-struct Volume { TerraAABB box; uint32_t index; };
-
-static inline float fmin_sel ( float a, float b ) { return a < b ? a : b; }
-static inline float fmax_sel ( float a, float b ) { return a > b ? a : b; }
-static TerraAABB empty_box() { TerraAABB b; b.min = { FLT_MAX, FLT_MAX, FLT_MAX }; b.max = { -FLT_MAX, -FLT_MAX, -FLT_MAX }; return b; }
-static void grow_by_triangle ( TerraAABB& b, const TerraTriangle& t ) {
-    const double eps = 1e-4;
-    b.min.x = ( float ) ( ( double ) fmin_sel ( fmin_sel ( fmin_sel ( b.min.x, t.a.x ), t.b.x ), t.c.x ) - eps );
-    b.min.y = ( float ) ( ( double ) fmin_sel ( fmin_sel ( fmin_sel ( b.min.y, t.a.y ), t.b.y ), t.c.y ) - eps );
-    b.min.z = ( float ) ( ( double ) fmin_sel ( fmin_sel ( fmin_sel ( b.min.z, t.a.z ), t.b.z ), t.c.z ) - eps );
-    b.max.x = ( float ) ( ( double ) fmax_sel ( fmax_sel ( fmax_sel ( b.max.x, t.a.x ), t.b.x ), t.c.x ) + eps );
-    b.max.y = ( float ) ( ( double ) fmax_sel ( fmax_sel ( fmax_sel ( b.max.y, t.a.y ), t.b.y ), t.c.y ) + eps );
-    b.max.z = ( float ) ( ( double ) fmax_sel ( fmax_sel ( fmax_sel ( b.max.z, t.a.z ), t.b.z ), t.c.z ) + eps );
-}
-static void grow_by_box ( TerraAABB& b, const TerraAABB& o ) {
-    const double eps = 1e-4;
-    b.min.x = fmin_sel ( b.min.x, o.min.x ); b.min.y = fmin_sel ( b.min.y, o.min.y ); b.min.z = fmin_sel ( b.min.z, o.min.z );
-    b.max.x = ( float ) ( ( double ) fmax_sel ( b.max.x, o.max.x ) + eps );
-    b.max.y = ( float ) ( ( double ) fmax_sel ( b.max.y, o.max.y ) + eps );
-    b.max.z = ( float ) ( ( double ) fmax_sel ( b.max.z, o.max.z ) + eps );
-}
-static float area ( const TerraAABB& b ) {
-    float w = b.max.x - b.min.x, h = b.max.y - b.min.y, d = b.max.z - b.min.z;
-    return 2 * ( w * d + w * h + d * h );
-}
-static float centre_x ( const TerraAABB& b ) { return ( b.min.x + b.max.x ) / 2; }
-
-static void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nodes, int& max_stack ) {
-    size_t n = 0;
-    for ( size_t j = 0; j < nobj; ++j ) n += objects[j].triangles_count;
-    std::vector<Volume> vol ( n );
-    TerraAABB scene_box = empty_box();
-    size_t p = 0;
-    for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < objects[j].triangles_count; ++i, ++p ) {
-        vol[p].box = empty_box();
-        grow_by_triangle ( scene_box, objects[j].triangles[i] );     // the scene box shrinks/grows by eps per triangle, as in the reference
-        grow_by_triangle ( vol[p].box, objects[j].triangles[i] );
-        vol[p].index = ( uint32_t ) ( ( int ) j | ( ( int ) i << 8 ) );
-    }
-    nodes.assign ( n > 1 ? n - 1 : 1, HostNode() );
-    memset ( nodes.data(), 0, nodes.size() * sizeof ( HostNode ) );
-    max_stack = 1;
-    if ( n < 2 ) {      // the reference cannot build these; emit a root with one (or no) leaf
-        nodes[0].type[0] = n == 1 ? 1 : 0; nodes[0].type[1] = 0;
-        if ( n == 1 ) { nodes[0].aabb[0] = vol[0].box; nodes[0].index[0] = ( int32_t ) vol[0].index; }
-        return;
-    }
-    std::stable_sort ( vol.begin(), vol.end(), [] ( const Volume & l, const Volume & r ) { return centre_x ( l.box ) > centre_x ( r.box ); } );
-    struct Task { int start, end, node; TerraAABB container; };
-    std::vector<Task> todo;
-    std::vector<float> la ( n ), ra ( n );
-    todo.push_back ( { 0, ( int ) n, 0, scene_box } );
-    int next_node = 1;
-    while ( !todo.empty() ) {
-        Task t = todo.back(); todo.pop_back();
-        const int cnt = t.end - t.start;
-        const Volume* v = vol.data() + t.start;
-        const float container_area = area ( t.container );
-        TerraAABB acc = empty_box();
-        for ( int i = 0; i < cnt; ++i ) { grow_by_box ( acc, v[i].box ); la[i] = area ( acc ); }
-        acc = empty_box();
-        for ( int i = cnt - 1; i >= 0; --i ) { grow_by_box ( acc, v[i].box ); ra[i] = area ( acc ); }
-        float best_cost = FLT_MAX; int best = -1;
-        for ( int i = 0; i < cnt; ++i ) {
-            const int lc = i + 1, rc = cnt - lc;
-            float cost = lc * la[i] / container_area + rc * ra[i] / container_area;
-            if ( cost < best_cost ) { best_cost = cost; best = i; }
-        }
-        if ( best < 0 ) best = 0;
-        if ( best > cnt - 2 ) best = cnt - 2;
-        const int split = best + t.start;
-        HostNode& nd = nodes[t.node];
-        if ( split == t.start ) {
-            nd.type[0] = 1; nd.aabb[0] = vol[t.start].box; nd.index[0] = ( int32_t ) vol[t.start].index;
-        } else {
-            TerraAABB b = empty_box();
-            for ( int i = t.start; i <= split; ++i ) grow_by_box ( b, vol[i].box );
-            nd.type[0] = -1; nd.aabb[0] = b; nd.index[0] = next_node;
-            todo.push_back ( { t.start, split + 1, next_node, b } );
-            ++next_node;
-        }
-        if ( split == t.end - 2 ) {
-            nd.type[1] = 1; nd.aabb[1] = vol[t.end - 1].box; nd.index[1] = ( int32_t ) vol[t.end - 1].index;
-        } else {
-            TerraAABB b = empty_box();
-            for ( int i = split + 1; i < t.end; ++i ) grow_by_box ( b, vol[i].box );
-            nd.type[1] = -1; nd.aabb[1] = b; nd.index[1] = next_node;
-            todo.push_back ( { split + 1, t.end, next_node, b } );
-            ++next_node;
-        }
-    }
-    nodes.resize ( ( size_t ) next_node );
-    // stack entries a ray can need: replay the traversal's push/pop order with every box hit
-    std::vector<int> st; st.reserve ( 64 ); st.push_back ( 0 );
-    while ( !st.empty() ) {
-        const HostNode& nd = nodes[ ( size_t ) st.back()]; st.pop_back();
-        for ( int i = 0; i < 2; ++i ) if ( nd.type[i] == -1 ) { st.push_back ( nd.index[i] ); max_stack = std::max ( max_stack, ( int ) st.size() ); }
-    }
-}
-} // namespace bvh
-
-// ---- fast tree: 3-axis binned SAH, BVH2, leaves of <= 4 triangles ----------
-// Built over the same per-triangle boxes as the reference (triangle bounds +- 1e-4) so every
-// triangle a ray can hit lies inside its ancestors' boxes; inner boxes are plain unions.
-#ifndef TERRA_FAST_LEAF_MAX      // triangles per leaf of the fast tree (the leaf word holds count-1 in 4 bits)
-#define TERRA_FAST_LEAF_MAX 4
-#endif
-namespace fastbvh {
-struct Prim { TerraAABB box; float c[3]; uint32_t soup; };
-struct Built { std::vector<DevNode> nodes; std::vector<uint32_t> order; int max_stack = 1; };
-
-static inline void grow ( TerraAABB& b, const TerraAABB& o ) {
-    b.min.x = std::min ( b.min.x, o.min.x ); b.min.y = std::min ( b.min.y, o.min.y ); b.min.z = std::min ( b.min.z, o.min.z );
-    b.max.x = std::max ( b.max.x, o.max.x ); b.max.y = std::max ( b.max.y, o.max.y ); b.max.z = std::max ( b.max.z, o.max.z );
-}
-static inline float half_area ( const TerraAABB& b ) {
-    float w = b.max.x - b.min.x, h = b.max.y - b.min.y, d = b.max.z - b.min.z;
-    return w * h + h * d + d * w;
-}
-static TerraAABB empty() { return bvh::empty_box(); }
-
-// returns the child word for the range [lo, hi) of prims, appending nodes as needed
-static uint32_t build_range ( std::vector<Prim>& prims, int lo, int hi, Built& out, int depth, int& max_depth );
-
-static uint32_t make_leaf ( int lo, int hi ) { return DEV_CHILD_LEAF | ( ( uint32_t ) ( hi - lo - 1 ) << 27 ) | ( uint32_t ) lo; }
-
-static void set_child ( DevNode& n, int k, const TerraAABB& b, uint32_t word ) {
-    float* mn = k == 0 ? n.min0 : n.min1; float* mx = k == 0 ? n.max0 : n.max1;
-    mn[0] = b.min.x; mn[1] = b.min.y; mn[2] = b.min.z; mx[0] = b.max.x; mx[1] = b.max.y; mx[2] = b.max.z;
-    n.child[k] = word; n.prim[k] = 0;
-}
-
-static Built build ( std::vector<Prim>& prims ) {
-    Built out;
-    const int n = ( int ) prims.size();
-    out.nodes.reserve ( ( size_t ) std::max ( 1, n ) );
-    out.nodes.push_back ( DevNode() );
-    memset ( &out.nodes[0], 0, sizeof ( DevNode ) );
-    struct Task { int lo, hi, node, slot, depth; };
-    // root node holds the whole scene as (child0 = everything, child1 = empty) unless it splits
-    std::vector<Task> todo;
-    int max_depth = 1;
-    auto bounds = [&] ( int lo, int hi ) { TerraAABB b = empty(); for ( int i = lo; i < hi; ++i ) grow ( b, prims[i].box ); return b; };
-    auto split = [&] ( int lo, int hi, int& mid ) -> bool {
-        const int cnt = hi - lo;
-        if ( cnt <= TERRA_FAST_LEAF_MAX ) return false;
-        float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-        for ( int i = lo; i < hi; ++i ) for ( int a = 0; a < 3; ++a ) { cmin[a] = std::min ( cmin[a], prims[i].c[a] ); cmax[a] = std::max ( cmax[a], prims[i].c[a] ); }
-        const int B = 16;
-        float best_cost = FLT_MAX; int best_axis = -1, best_bin = -1;
-        for ( int a = 0; a < 3; ++a ) {
-            float ext = cmax[a] - cmin[a];
-            if ( ! ( ext > 0.f ) ) continue;
-            TerraAABB bb[B]; int bc[B];
-            for ( int b = 0; b < B; ++b ) { bb[b] = empty(); bc[b] = 0; }
-            const float scale = ( float ) B / ext;
-            for ( int i = lo; i < hi; ++i ) { int b = std::min ( B - 1, std::max ( 0, ( int ) ( ( prims[i].c[a] - cmin[a] ) * scale ) ) ); grow ( bb[b], prims[i].box ); ++bc[b]; }
-            float la[B], ra[B]; int lc[B], rc[B];
-            TerraAABB acc = empty(); int cacc = 0;
-            for ( int b = 0; b < B; ++b ) { grow ( acc, bb[b] ); cacc += bc[b]; la[b] = cacc ? half_area ( acc ) : 0.f; lc[b] = cacc; }
-            acc = empty(); cacc = 0;
-            for ( int b = B - 1; b >= 0; --b ) { grow ( acc, bb[b] ); cacc += bc[b]; ra[b] = cacc ? half_area ( acc ) : 0.f; rc[b] = cacc; }
-            for ( int b = 0; b < B - 1; ++b ) {
-                if ( lc[b] == 0 || rc[b + 1] == 0 ) continue;
-                float cost = la[b] * ( float ) lc[b] + ra[b + 1] * ( float ) rc[b + 1];
-                if ( cost < best_cost ) { best_cost = cost; best_axis = a; best_bin = b; }
-            }
-        }
-        if ( best_axis < 0 ) {      // all centroids coincide: split in the middle
-            mid = lo + cnt / 2;
-            return true;
-        }
-        const float ext = cmax[best_axis] - cmin[best_axis], scale = ( float ) B / ext, c0 = cmin[best_axis];
-        const int a = best_axis, bsel = best_bin;
-        auto it = std::partition ( prims.begin() + lo, prims.begin() + hi, [&] ( const Prim & p ) {
-            int b = std::min ( B - 1, std::max ( 0, ( int ) ( ( p.c[a] - c0 ) * scale ) ) ); return b <= bsel; } );
-        mid = ( int ) ( it - prims.begin() );
-        if ( mid == lo || mid == hi ) mid = lo + cnt / 2;
-        return true;
-    };
-    if ( n == 0 ) { out.nodes[0].child[0] = DEV_CHILD_EMPTY; out.nodes[0].child[1] = DEV_CHILD_EMPTY; out.max_stack = 1; return out; }
-    int mid = 0;
-    if ( !split ( 0, n, mid ) ) {
-        set_child ( out.nodes[0], 0, bounds ( 0, n ), make_leaf ( 0, n ) );
-        out.nodes[0].child[1] = DEV_CHILD_EMPTY;
-        out.max_stack = 1;
-    } else {
-        todo.push_back ( { 0, mid, 0, 0, 1 } );
-        todo.push_back ( { mid, n, 0, 1, 1 } );
-        while ( !todo.empty() ) {
-            Task t = todo.back(); todo.pop_back();
-            max_depth = std::max ( max_depth, t.depth );
-            TerraAABB b = bounds ( t.lo, t.hi );
-            int m = 0;
-            if ( !split ( t.lo, t.hi, m ) ) { set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, make_leaf ( t.lo, t.hi ) ); continue; }
-            uint32_t idx = ( uint32_t ) out.nodes.size();
-            out.nodes.push_back ( DevNode() );
-            memset ( &out.nodes.back(), 0, sizeof ( DevNode ) );
-            set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, idx );
-            todo.push_back ( { t.lo, m, ( int ) idx, 0, t.depth + 1 } );
-            todo.push_back ( { m, t.hi, ( int ) idx, 1, t.depth + 1 } );
-        }
-        out.max_stack = max_depth + 2;     // ordered traversal: at most one extra pending entry per level
-    }
-    out.order.resize ( ( size_t ) n );
-    for ( int i = 0; i < n; ++i ) out.order[ ( size_t ) i] = prims[ ( size_t ) i].soup;
-    return out;
-}
-} // namespace fastbvh
 
 static float triangle_area ( const TerraTriangle& t ) {
     TerraFloat3 ab = terra_subf3 ( &t.b, &t.a ), ac = terra_subf3 ( &t.c, &t.a );

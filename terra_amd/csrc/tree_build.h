@@ -1,0 +1,24 @@
+// tree_build.h -- host-side tree builders of libterra_amd.so (implemented in tree_build.cpp).
+//   bvh::build      the reference's own tree, node for node (reference src/TerraBVH.c:24-35,70-244)
+//   fastbvh::build  the optional 3-axis binned-SAH tree of DESIGN.md "Fast tree" 
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "../../include/Terra.h"
+#include "dev_types.h"
+
+struct HostNode { TerraAABB aabb[2]; int32_t index[2]; int32_t type[2]; };   // reference node layout (src/TerraBVH.h:13-17)
+static_assert ( sizeof ( HostNode ) == 64, "reference node is 64 bytes" );
+
+namespace bvh {
+TerraAABB empty_box();
+void grow_by_triangle ( TerraAABB& box, const TerraTriangle& t );      // union with the triangle's box, inflated by 1e-4 as the reference does
+// builds the reference's tree over all objects' triangles; max_stack = stack entries its traversal can need
+void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nodes, int& max_stack );
+}
+
+namespace fastbvh {
+struct Prim { TerraAABB box; float c[3]; uint32_t soup; };
+struct Built { std::vector<DevNode> nodes; std::vector<uint32_t> order; int max_stack = 1; };
+Built build ( std::vector<Prim>& prims );      // reorders prims into leaf order
+}

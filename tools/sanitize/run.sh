@@ -9,7 +9,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$ROOT/terra_amd/build_asan; mkdir -p $OUT
 g++ -std=c++17 -O1 -g -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/terra_amd/csrc -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -w \
-    -shared -o $OUT/libterra_host_asan.so $ROOT/terra_amd/csrc/scene_host.cpp $ROOT/tools/sanitize/stub_launchers.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+    -shared -o $OUT/libterra_host_asan.so $ROOT/terra_amd/csrc/scene_host.cpp $ROOT/terra_amd/csrc/tree_build.cpp $ROOT/tools/sanitize/stub_launchers.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 gcc -std=gnu11 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include -shared -o $OUT/liboracle_asan.so $ROOT/oracle/terra_oracle.c -lm
 export LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0
 python3 $ROOT/tools/sanitize/drive_host.py $OUT/libterra_host_asan.so 2>&1 | grep -v "no HIP device" | tail -5
