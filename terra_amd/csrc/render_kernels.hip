@@ -173,6 +173,38 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #define TERRA_WAVES_FOR(I, K, M) ( ( M ) == 2 ? ( ( K ) == 1 ? ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_LIGHT : TERRA_WAVES_FAST_TREE ) : ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_GENERIC_LIGHT : TERRA_WAVES_FAST_TREE_GENERIC ) ) \
                                  : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : TERRA_WAVES_LIGHT ) \
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
+// ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
+// Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
+struct LaneTraversal { RayState st; Closest best; int top, nleaf; bool traversing, regular; };
+TD LaneTraversal lane_traversal_idle ( const Ray& any_ray ) {
+    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.top = 0; t.nleaf = 0; t.traversing = false; t.regular = true;
+    return t;
+}
+// puts `ray` in flight: the origin offset terra_scene_raycast applies (src/Terra.c:1629-1630), ray state, empty closest hit, root on the stack
+template <int COUNT>
+TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
+    Ray r = ray; r.o = r.o + r.d * 0.001f;
+    t.st = ray_state_init ( r );
+    t.regular = ray_is_regular ( r );
+    t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu;
+    T.stack[0] = 0; t.top = 1; t.nleaf = 0;
+    t.traversing = true;
+    if ( COUNT ) ++c.rays;
+}
+// advances every traversing lane until 1 / 2^TERRA_DECOUPLED_EXIT_SHIFT of them have finished; false when no lane is traversing
+template <int COUNT, int MODE>
+TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
+    const int n_trav = __popcll ( __ballot ( t.traversing ) );
+    if ( n_trav == 0 ) return false;
+    int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+    const int exit_active = n_trav - quota;
+    Ray r = ray; r.o = r.o + r.d * 0.001f;
+    V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
+    if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.st, o_perm, t.best, t.top, t.nleaf, t.traversing, exit_active, c );
+    else traverse_resume<COUNT, MODE, false> ( T, r, t.st, o_perm, t.best, t.top, t.nleaf, t.traversing, exit_active, c );
+    return true;
+}
+
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
@@ -203,42 +235,41 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     if constexpr ( TERRA_DECOUPLED_MIS ( INTEGRATOR, MODE, KINDS ) ) {
         // Decoupled loop for Direct + MIS: like the Direct one below with two shadow jobs per shaded hit, in the reference's
         // order -- A: the ray to the light sample, B: the BSDF-sampled ray (mis_prepare / mis_finish_b).
-        RayState st = ray_state_init ( ray );
-        Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
-        int top = 0, nleaf = 0, job = 0;                         // job: 0 path segment, 1 shadow ray A, 2 shadow ray B
-        bool traversing = false, done = !valid, have_ray = false, regular = true, cont = false;
+        LaneTraversal lt = lane_traversal_idle ( ray );
+        int job = 0;                                             // 0 path segment, 1 shadow ray A, 2 shadow ray B
+        bool done = !valid, have_ray = false, cont = false;
         MisPending pend; pend.a_vis = pend.a_hid = pend.f2 = pend.p = pend.t_before = v3 ( 0, 0, 0 ); pend.expected = 0; pend.bpdf2 = pend.cos2 = 0.f; pend.light_object = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 ), b_o = v3 ( 0, 0, 0 ), b_d = v3 ( 0, 0, 1 ), lo_i = v3 ( 0, 0, 0 );
         for ( ;; ) {
-            if ( !traversing && !done ) {
+            if ( !lt.traversing && !done ) {
                 bool start = false;
                 if ( have_ray && job != 0 ) {
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
-                    const bool hit = best.tri != 0xffffffffu;
+                    const bool hit = lt.best.tri != 0xffffffffu;
                     Surface lsf; uint32_t object = 0, tri_in_object = 0, nattr = 0;
-                    V3 point = hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
+                    V3 point = hit ? r.o + r.d * lt.best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
                     if ( hit ) {
-                        if ( job == 2 ) surface_init<MODE, KINDS> ( T, best.tri, point, lsf, object, tri_in_object, nattr );
-                        else { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * best.tri]; object = __float_as_uint ( t0.w ); nattr = T.sc.mats[object].attributes_count; }
+                        if ( job == 2 ) surface_init<MODE, KINDS> ( T, lt.best.tri, point, lsf, object, tri_in_object, nattr );
+                        else { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * lt.best.tri]; object = __float_as_uint ( t0.w ); nattr = T.sc.mats[object].attributes_count; }
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
                     }
                     if ( job == 1 ) {                            // A came back: pick its outcome, send B
-                        lo_i = best.tri == pend.expected ? pend.a_vis : pend.a_hid;
+                        lo_i = lt.best.tri == pend.expected ? pend.a_vis : pend.a_hid;
                         ray = make_ray ( b_o, b_d ); job = 2; start = true;
                     } else {                                     // B came back: the integrator's value is complete
-                        Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, best.tri, point, lsf, ray.d );
+                        Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, lt.best.tri, point, lsf, ray.d );
                         job = 0;
                         if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
                         else { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false; }
                     }
                 } else if ( have_ray ) {                         // a path segment came back
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
-                    if ( best.tri != 0xffffffffu ) {
+                    if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        V3 point = r.o + r.d * best.depth;
+                        V3 point = r.o + r.d * lt.best.depth;
                         uint32_t object, tri_in_object, nattr;
-                        surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+                        surface_init<MODE, KINDS> ( T, lt.best.tri, point, sf, object, tri_in_object, nattr );
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
                         V3 wo = neg ( ray.d );
@@ -274,24 +305,9 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; job = 0; start = true;
                     }
                 }
-                if ( start ) {
-                    Ray r = ray; r.o = r.o + r.d * 0.001f;
-                    st = ray_state_init ( r );
-                    regular = ray_is_regular ( r );
-                    best.depth = FLT_MAX; best.tri = 0xffffffffu;
-                    T.stack[0] = 0; top = 1; nleaf = 0;
-                    traversing = true; have_ray = true;
-                    if ( COUNT ) ++c.rays;
-                }
+                if ( start ) { lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
             }
-            const int n_trav = __popcll ( __ballot ( traversing ) );
-            if ( n_trav == 0 ) break;
-            int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
-            const int exit_active = n_trav - quota;
-            Ray r = ray; r.o = r.o + r.d * 0.001f;
-            V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-            if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
-            else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) ) break;      // nobody traversing => everybody is done
         }
     } else if constexpr ( TERRA_DECOUPLED_DIRECT ( INTEGRATOR, MODE, KINDS ) ) {
         // Decoupled loop for the Direct integrator. A lane's ray in flight is either a path segment (MAIN) or the shadow
@@ -299,31 +315,29 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // shadow test (direct_prepare), samples the BSDF and plays Russian roulette -- all stream draws in the reference's
         // order -- parks the continuation ray and sends the shadow ray; when that returns, the matching outcome is added
         // and the continuation (or the pixel's next sample) starts. Same rays, same draws, same sums as integrate_direct.
-        RayState st = ray_state_init ( ray );
-        Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
-        int top = 0, nleaf = 0;
-        bool traversing = false, done = !valid, have_ray = false, regular = true, shadow = false, cont = false;
+        LaneTraversal lt = lane_traversal_idle ( ray );
+        bool done = !valid, have_ray = false, shadow = false, cont = false;
         DirectPending pend; pend.vis = pend.hid = v3 ( 0, 0, 0 ); pend.expected = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 );
         for ( ;; ) {
-            if ( !traversing && !done ) {
+            if ( !lt.traversing && !done ) {
                 bool start = false;
                 if ( have_ray && shadow ) {                      // the shadow ray came back
-                    if ( best.tri != 0xffffffffu ) {             // (its hit counts as a surface init, as in the coupled form)
+                    if ( lt.best.tri != 0xffffffffu ) {             // (its hit counts as a surface init, as in the coupled form)
                         if ( COUNT ) ++c.hits;
-                        if ( COUNT == 2 ) { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * best.tri]; c.attr_fetches += T.sc.mats[__float_as_uint ( t0.w )].attributes_count + 1; }
+                        if ( COUNT == 2 ) { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * lt.best.tri]; c.attr_fetches += T.sc.mats[__float_as_uint ( t0.w )].attributes_count + 1; }
                     }
-                    Lo = Lo + ( best.tri == pend.expected ? pend.vis : pend.hid );
+                    Lo = Lo + ( lt.best.tri == pend.expected ? pend.vis : pend.hid );
                     shadow = false;
                     if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
                     else { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false; }
                 } else if ( have_ray ) {                         // a path segment came back
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
-                    if ( best.tri != 0xffffffffu ) {
+                    if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        V3 point = r.o + r.d * best.depth;
+                        V3 point = r.o + r.d * lt.best.depth;
                         uint32_t object, tri_in_object, nattr;
-                        surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+                        surface_init<MODE, KINDS> ( T, lt.best.tri, point, sf, object, tri_in_object, nattr );
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
                         V3 wo = neg ( ray.d );
@@ -359,45 +373,28 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; start = true;
                     }
                 }
-                if ( start ) {
-                    Ray r = ray; r.o = r.o + r.d * 0.001f;
-                    st = ray_state_init ( r );
-                    regular = ray_is_regular ( r );
-                    best.depth = FLT_MAX; best.tri = 0xffffffffu;
-                    T.stack[0] = 0; top = 1; nleaf = 0;
-                    traversing = true; have_ray = true;
-                    if ( COUNT ) ++c.rays;
-                }
+                if ( start ) { lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
             }
-            const int n_trav = __popcll ( __ballot ( traversing ) );
-            if ( n_trav == 0 ) break;
-            int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
-            const int exit_active = n_trav - quota;
-            Ray r = ray; r.o = r.o + r.d * 0.001f;
-            V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-            if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
-            else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) ) break;      // nobody traversing => everybody is done
         }
     } else if constexpr ( TERRA_DECOUPLED ( INTEGRATOR, MODE ) ) {
         // Decoupled loop (scenes read from global memory, integrators without nested raycasts): a lane is either
-        // traversing its current ray or waiting to be shaded. The resumable traversal returns as soon as a quarter of
+        // traversing its current ray or waiting to be shaded. The resumable traversal returns as soon as 1/16 of
         // the lanes that entered it have finished; those are shaded and handed their next ray (continuation or the
         // pixel's next camera sample) while the others keep their traversal state. Per pixel nothing changes: same
         // rays, same stream draws, same accumulation order.
-        RayState st = ray_state_init ( ray );
-        Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
-        int top = 0, nleaf = 0;
-        bool traversing = false, done = !valid, have_ray = false, regular = true;
+        LaneTraversal lt = lane_traversal_idle ( ray );
+        bool done = !valid, have_ray = false;
         for ( ;; ) {
-            if ( !traversing && !done ) {
+            if ( !lt.traversing && !done ) {
                 bool next = false;
                 if ( have_ray ) {
                     Ray r = ray; r.o = r.o + r.d * 0.001f;           // the offset scene_raycast applies (src/Terra.c:1629-1630)
-                    if ( best.tri != 0xffffffffu ) {
+                    if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        V3 point = r.o + r.d * best.depth;
+                        V3 point = r.o + r.d * lt.best.depth;
                         uint32_t object, tri_in_object, nattr;
-                        surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+                        surface_init<MODE, KINDS> ( T, lt.best.tri, point, sf, object, tri_in_object, nattr );
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
                         V3 wo = neg ( ray.d );
@@ -430,24 +427,9 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; next = true;
                     }
                 }
-                if ( next ) {
-                    Ray r = ray; r.o = r.o + r.d * 0.001f;
-                    st = ray_state_init ( r );
-                    regular = ray_is_regular ( r );
-                    best.depth = FLT_MAX; best.tri = 0xffffffffu;
-                    T.stack[0] = 0; top = 1; nleaf = 0;
-                    traversing = true; have_ray = true;
-                    if ( COUNT ) ++c.rays;
-                }
+                if ( next ) { lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
             }
-            const int n_trav = __popcll ( __ballot ( traversing ) );
-            if ( n_trav == 0 ) break;                // nobody traversing => everybody is done
-            int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
-            const int exit_active = n_trav - quota;
-            Ray r = ray; r.o = r.o + r.d * 0.001f;
-            V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-            if ( __all ( !traversing || regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
-            else traverse_resume<COUNT, MODE, false> ( T, r, st, o_perm, best, top, nleaf, traversing, exit_active, c );
+            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) ) break;      // nobody traversing => everybody is done
         }
     } else {
     bool alive = false;
