@@ -100,24 +100,40 @@ def usable_cores() -> int:
     return n
 
 
-def _time_cpu(lib, prefix, d, cores, seconds_budget):
-    """one CPU renderer (same C entry-point shape for the compiled reference and the oracle) over a centred crop at full spp"""
+def _time_cpu(lib, prefix, d, cores, seconds_budget, rows_total=None):
+    """one CPU renderer (same C entry-point shape for the compiled reference and the oracle) over a stratified sample of the
+    frame at full spp: up to 8 full-width bands evenly spaced over the height, so that the sample's mix of cheap (background)
+    and expensive (inside the box) pixels is the frame's. Returns (Msamples/s, description, rows used)."""
     f = lib.fn(prefix + "render_pixels_mt", None, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 4 + [C.c_uint64, C.c_void_p, C.c_int])
     scene = scenes.build_scene(lib, d)
     cam = scenes.camera_of(d)
     fb = api.Framebuffer(lib, d.width, d.height)
-    # calibrate on a thin strip, then size the crop for ~seconds_budget
-    cw = d.width; x0 = 0; y0 = d.height // 2            # full-width band around the middle row
-    rows0 = max(4, cores)
-    t = time.perf_counter(); f(C.byref(cam), scene, C.byref(fb.fb), x0, y0, cw, rows0, scenes.FRAME_SEED, None, cores); dt = time.perf_counter() - t
-    rate = cw * rows0 * d.spp / max(dt, 1e-6)
-    rows = int(max(8, min(d.height, seconds_budget * rate / (cw * d.spp))))
-    y1 = max(0, d.height // 2 - rows // 2)
-    fb.clear()
-    t = time.perf_counter(); f(C.byref(cam), scene, C.byref(fb.fb), x0, y1, cw, rows, scenes.FRAME_SEED, None, cores); dt = time.perf_counter() - t
-    val = cw * rows * d.spp / dt / 1e6
+    BANDS = max(1, min(8, cores // 2))
+    per_band_threads = max(1, cores // BANDS)
+
+    def run(rows):
+        # the bands render concurrently (ctypes drops the GIL), each on its share of the cores, so short bands still use every core
+        import threading
+        per = max(1, rows // BANDS); fb.clear()
+        def one(b):
+            y0 = min(d.height - per, max(0, int((b + 0.5) * d.height / BANDS) - per // 2))
+            f(C.byref(cam), scene, C.byref(fb.fb), 0, y0, d.width, per, scenes.FRAME_SEED, None, per_band_threads)
+        ths = [threading.Thread(target=one, args=(b,)) for b in range(BANDS)]
+        t = time.perf_counter(); [th.start() for th in ths]; [th.join() for th in ths]
+        return per * BANDS, time.perf_counter() - t
+
+    if rows_total is None:          # size the sample for ~seconds_budget: a thin pass, then one re-sizing pass if it came out short
+        rows, dt = run(BANDS * 4 * per_band_threads)
+        rows_total = int(min(d.height, max(BANDS, rows * seconds_budget / max(dt, 1e-3))))
+        rows, dt = run(rows_total)
+        if dt < 0.6 * seconds_budget and rows < d.height:
+            rows_total = int(min(d.height, rows * seconds_budget / max(dt, 1e-3)))
+            rows, dt = run(rows_total)
+    else:
+        rows, dt = run(rows_total)
+    val = d.width * rows * d.spp / dt / 1e6
     fb.destroy(); lib.scene_destroy(scene)
-    return val, f"{cw}x{rows} band at y={y1} of the {d.width}x{d.height} frame, full {d.spp} spp, {dt:.1f} s"
+    return val, f"{BANDS} full-width bands of {rows // BANDS} rows evenly spaced over the {d.width}x{d.height} frame ({rows} rows), full {d.spp} spp, {dt:.1f} s", rows
 
 
 def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 12.0):
@@ -128,10 +144,10 @@ def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 12.0):
     cores = usable_cores()
     subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
     orc = api.TerraLib(ROOT / "oracle" / "liboracle.so", "orc_")
-    port, port_sample = _time_cpu(orc, "orc_", d, cores, seconds_budget)
+    port, port_sample, rows = _time_cpu(orc, "orc_", d, cores, seconds_budget)
     ref_so = ROOT / "oracle" / "_ref" / "libterra_ref.so"
     if ref_so.exists() and all(o.material.kind in ("diffuse", "phong") for o in d.objects):    # the reference has no GGX/glass preset
-        val, sample = _time_cpu(api.TerraLib(ref_so, "terra_"), "ref_", d, cores, seconds_budget)
+        val, sample, _ = _time_cpu(api.TerraLib(ref_so, "terra_"), "ref_", d, cores, seconds_budget, rows_total=rows)     # the same rows as the oracle's run
         return {"value": round(val, 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
                 "sample": sample + f", oracle/_ref/libterra_ref.so (the reference's sources, gcc -O2, one terra_render call per pixel) on {cores} threads",
                 "port_value": round(port, 3), "port_sample": port_sample + f", oracle/liboracle.so on {cores} threads"}
