@@ -124,8 +124,9 @@ def _time_cpu(lib, prefix, d, cores, seconds_budget, rows_total=None):
 
     if rows_total is None:          # size the sample for ~seconds_budget: a thin pass, then one re-sizing pass if it came out short
         rows, dt = run(BANDS * 4 * per_band_threads)
-        rows_total = int(min(d.height, max(BANDS, rows * seconds_budget / max(dt, 1e-3))))
-        rows, dt = run(rows_total)
+        if dt < 0.6 * seconds_budget:           # (a heavy workload can exhaust the budget with the thin pass alone: then that is the sample)
+            rows_total = int(min(d.height, max(BANDS, rows * seconds_budget / max(dt, 1e-3))))
+            rows, dt = run(rows_total)
         if dt < 0.6 * seconds_budget and rows < d.height:
             rows_total = int(min(d.height, rows * seconds_budget / max(dt, 1e-3)))
             rows, dt = run(rows_total)
