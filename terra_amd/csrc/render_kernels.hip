@@ -509,6 +509,9 @@ size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_n
 #ifndef TERRA_LDS_CU_KB
 #define TERRA_LDS_CU_KB 158
 #endif
+#ifndef TERRA_LEAF_CAP_MIN       // smallest leaf list worth an extra resident block (with the decoupled loop, hall: 5 blocks x 6 entries
+#define TERRA_LEAF_CAP_MIN 6     // 391 ms vs 4 blocks x 14 entries 400 ms, Direct 473 vs 487 ms; profiles/r01_measurements/ab_lc*.log)
+#endif
 #ifndef TERRA_LDS_BUDGET
 #define TERRA_LDS_BUDGET ( 32 * 1024 )
 #endif
@@ -528,7 +531,7 @@ void terra_plan_lds ( DevRenderParams& p ) {
     p.lds_mode = 0; p.lds_nodes = 0; p.lds_tris = 0;
     for ( int blocks = 5; blocks >= 1; --blocks ) {
         int room = TERRA_LDS_CU_KB / blocks - ( int ) depth - TERRA_AUX_WORDS;       // KB per block left for the leaf list (2 KB of slack per CU)
-        if ( room >= 8 || blocks == 1 ) { p.leaf_cap = ( uint32_t ) ( room > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : ( room < 4 ? 4 : room ) ); break; }
+        if ( room >= TERRA_LEAF_CAP_MIN || blocks == 1 ) { p.leaf_cap = ( uint32_t ) ( room > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : ( room < 4 ? 4 : room ) ); break; }
     }
 }
 
