@@ -99,6 +99,9 @@ int terra_amd_reset_stats ( HTerraScene scene );
 /* Debug builds only (-DTERRA_CHECK_BOUNDS=1 verifies every traversal-stack and leaf-list write against the sizes
    the host planned): number of writes refused since the last reset; the shipped build always reports 0. -1 = no device. */
 long long terra_amd_debug_faults ( HTerraScene scene );
+/* Debug builds only (-DTERRA_PHASE_STATS=1, tools/phase_stats.py): 16 lane-occupancy counters of the render kernel's
+   phases since the last reset (wave-level iterations and lanes active in them); the shipped build reports zeros. */
+int terra_amd_debug_counters ( HTerraScene scene, unsigned long long* out16 );
 
 /* Flattened-scene facts after commit (for tests and the roofline model). */
 typedef struct {

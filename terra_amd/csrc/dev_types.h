@@ -115,7 +115,8 @@ struct DevScene {
 #define TERRA_KIND_TEX 32
 
 // indices into the device counter array (uint64 each); mirrors TerraAmdStats
-enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrFaults, kCtrCount };   // kCtrFaults: only written by TERRA_CHECK_BOUNDS builds
+enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrFaults,
+       kCtrDbg0, kCtrDbgLast = kCtrDbg0 + 15, kCtrCount };   // kCtrFaults: only written by TERRA_CHECK_BOUNDS builds; kCtrDbg*: only by TERRA_PHASE_STATS builds (lane-occupancy study)
 
 struct DevRenderParams {
     DevScene scene;

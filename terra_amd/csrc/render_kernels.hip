@@ -436,14 +436,17 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     while ( true ) {
         if ( !alive ) {
             if ( !valid || s == p.chunk_spp ) break;
+            PS_WAVE ( c, kPsCamIter ); PS_LANE ( c, kPsCamLanes );
             float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
             ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
             Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++s;
         }
         Surface sf;
+        PS_WAVE ( c, kPsRayIter ); PS_LANE ( c, kPsRayLanes );
         RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
         bool end = !h.hit;
         if ( h.hit ) {
+            PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
             V3 wo = neg ( ray.d );
             Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
             float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
@@ -486,6 +489,13 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         if ( COUNT == 2 && p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
     }
     if ( COUNT ) wave_flush_counters<COUNT> ( c, p.counters, p.lean_attr_per_hit );
+#if TERRA_PHASE_STATS
+    for ( int k = 0; k < 16; ++k ) {
+        unsigned long long x = c.ps[k];
+        for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
+        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &p.counters[kCtrDbg0 + k], x );
+    }
+#endif
 }
 
 // ---- launch -------------------------------------------------------------------

@@ -599,6 +599,14 @@ extern "C" long long terra_amd_debug_faults ( HTerraScene h ) {
     if ( hipSetDevice ( s->device ) != hipSuccess || hipMemcpy ( &v, s->d_counters + kCtrFaults, sizeof v, hipMemcpyDeviceToHost ) != hipSuccess ) return -1;
     return ( long long ) v;
 }
+extern "C" int terra_amd_debug_counters ( HTerraScene h, unsigned long long* out16 ) {
+    // phase occupancy counters of a TERRA_PHASE_STATS build (tools/phase_stats.py); all zero in the shipped build
+    Scene* s = S ( h );
+    if ( !s->device_ok || !out16 ) return fail ( kTerraAmdErrNotCommitted, "scene has no device replica" );
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMemcpy ( out16, s->d_counters + kCtrDbg0, 16 * sizeof ( unsigned long long ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
+    return 0;
+}
 extern "C" int terra_amd_reset_stats ( HTerraScene h ) {
     Scene* s = S ( h );
     if ( !s->device_ok ) return fail ( kTerraAmdErrNotCommitted, "scene has no device replica" );

@@ -75,8 +75,31 @@ struct RayState { float shearx, sheary, scalez; int ix, iy, iz; };
 // Not counted on the device because the host can derive them exactly: slab tests
 // (= 2*nodes - tri_tests: every child of a popped node is either slab-tested or, if a
 // leaf, triangle-tested), camera samples and pixels (tile geometry x spp).
-struct Counters { uint32_t rays, nodes, tri_tests, hits, rand_calls, attr_fetches; };
-TD Counters counters_zero() { Counters c; c.rays = c.nodes = c.tri_tests = c.hits = c.rand_calls = c.attr_fetches = 0; return c; }
+#ifndef TERRA_PHASE_STATS          // lane-occupancy study builds (tools/phase_stats.py): per-phase wave iterations / active lanes
+#define TERRA_PHASE_STATS 0
+#endif
+struct Counters {
+    uint32_t rays, nodes, tri_tests, hits, rand_calls, attr_fetches;
+#if TERRA_PHASE_STATS
+    uint32_t ps[16];
+#endif
+};
+TD Counters counters_zero() {
+    Counters c; c.rays = c.nodes = c.tri_tests = c.hits = c.rand_calls = c.attr_fetches = 0;
+#if TERRA_PHASE_STATS
+    for ( int i = 0; i < 16; ++i ) c.ps[i] = 0;
+#endif
+    return c;
+}
+#if TERRA_PHASE_STATS
+// PS_WAVE: +1 per wave (the first active lane counts); PS_LANE: +1 per active lane
+#define PS_WAVE(c, k) do { if ( ( int ) ( threadIdx.x & 63 ) == __ffsll ( ( long long ) __ballot ( 1 ) ) - 1 ) ++( c ).ps[k]; } while ( 0 )
+#define PS_LANE(c, k) do { ++( c ).ps[k]; } while ( 0 )
+#else
+#define PS_WAVE(c, k) do { } while ( 0 )
+#define PS_LANE(c, k) do { } while ( 0 )
+#endif
+enum { kPsRayIter = 0, kPsNodeIter, kPsLeafIter, kPsShadeIter, kPsCamIter, kPsCamLanes, kPsRayLanes, kPsShadeLanes, kPsNodeLanes, kPsLeafLanes, kPsDrainIter };
 
 // -----------------------------------------------------------------------------
 // camera
@@ -298,7 +321,9 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     int top = 1, nleaf = 0;
     T.stack[0] = 0;
     for ( ;; ) {
+        PS_WAVE ( c, kPsDrainIter );
         while ( top > 0 && nleaf <= T.leaf_cap - 2 ) {
+            PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
             uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
             float4 q0, q1, q2, q3;
             if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
@@ -314,6 +339,7 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
             if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
         }
         for ( int i = 0; i < nleaf; ++i ) {
+            PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
             uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
             float pa[3], pb[3], pc[3];
             if ( MODE == 1 ) {

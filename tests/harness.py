@@ -278,18 +278,27 @@ class Unit:
         buf = (C.c_uint32 * (16 * n)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32).reshape(n, 16).copy()
 
-    def render_pixels(self, d: scenes.SceneDesc, passes=1, frame_seed=scenes.FRAME_SEED, rect=None, want_calls=True):
-        """Full per-pixel-stream render through this backend's CPU path (ref/orc only)."""
+    def render_pixels(self, d: scenes.SceneDesc, passes=1, frame_seed=scenes.FRAME_SEED, rect=None, want_calls=True, threads=0, sum_calls=False):
+        """Full per-pixel-stream render through this backend's CPU path (ref/orc only).
+        threads > 0: the *_render_pixels_mt entry (rows dealt to pthreads; per-pixel streams make the result thread independent)."""
         assert self.kind in ("ref", "orc")
-        f = self._f("render_pixels", None, RENDER_PIXELS_SIG)
+        if threads > 0:
+            fmt = self._f("render_pixels_mt", None, RENDER_PIXELS_SIG + [C.c_int])
+            f = lambda *a: fmt(*a, threads)
+        else:
+            f = self._f("render_pixels", None, RENDER_PIXELS_SIG)
         scene = scenes.build_scene(self.L, d)
         fb = api.Framebuffer(self.L, d.width, d.height)
         cam = scenes.camera_of(d)
         calls = np.zeros((d.height, d.width), np.uint32)
         x, y, w, h = rect if rect else (0, 0, d.width, d.height)
+        total = np.zeros((d.height, d.width), np.uint64)
         for _ in range(passes):
             f(C.byref(cam), scene, C.byref(fb.fb), x, y, w, h, frame_seed, calls.ctypes.data if want_calls else None)
-        out = dict(pixels=fb.pixels.copy(), acc=fb.results["acc"].copy(), samples=fb.results["samples"].copy(), rand_calls=calls)
+            total += calls
+        # rand_calls: the LAST pass's per-pixel stream-B draws (what a plain device call reports), or with sum_calls the
+        # total over the passes (what one split device call reports: its chunks are the passes)
+        out = dict(pixels=fb.pixels.copy(), acc=fb.results["acc"].copy(), samples=fb.results["samples"].copy(), rand_calls=total if sum_calls else calls)
         fb.destroy()
         self.L.scene_destroy(scene)
         return out
