@@ -4,33 +4,36 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1] -- the Cornell box at
-1920x1080, 512 spp, max 8 bounces (Simple integrator, random sampler, jitter 0.5,
-tonemap None) -- rendered through the product's
-device-resident entry point terra_amd_render_device[_sharded] (the framebuffer
-is already in HBM when the timed region starts; terra_render()'s PCIe-inclusive
-rate is reported in DESIGN.md, never here).
+`python bench.py --gpus N` with N > 1 from a bare shell starts the N ranks itself: before anything touches the GPU it
+spawns `python -m torch.distributed.run ...` as a CHILD process, relays the child's JSON line and exits with its code.
 
-A step = one pass of the hot path over the whole frame: every pixel receives
-spp more samples. With N ranks (one process per GPU) the frame's 64x64 tiles are
-dealt round-robin to the ranks (t % N == rank), each rank renders its tiles on
-its own scene replica, and ONE gather (RCCL over xGMI) moves the packed tiles to
-rank 0, which unpacks them into the full frame. Total work is fixed as N grows:
-"scaling": "strong". value = frame samples * K / max-over-ranks wall time.
-Every rank count renders with the same sample split (terra_amd_set_sample_split, default 8 lanes per pixel:
-the frame of 8 successive 64-spp calls), so the image does not depend on N and a 1/8 share of the frame
-still fills a GPU.
+Workload (config.workload): BASELINE.json configs[1] -- the Cornell box at 1920x1080, 512 spp, max 8 bounces (Simple
+integrator, random sampler, jitter 0.5, tonemap None) -- rendered through the product's
+device-resident entry point terra_amd_render_device[_sharded] (the framebuffer is already in HBM when the timed region
+starts; terra_render()'s PCIe-inclusive rate is reported in DESIGN.md, never here).
+
+A step = one pass of the hot path over the whole frame: every pixel receives spp more samples. With N ranks (one process
+per GPU) the frame's 64x64 tiles are dealt round-robin to the ranks (t % N == rank), each rank renders its tiles on its own
+scene replica, and ONE gather (RCCL over xGMI; terra_amd.runtime.gather_frame, the function the gloo test covers) moves the
+packed tiles to rank 0, which unpacks them into the full frame. Pack, gather and unpack run on a second stream: the next
+step's render (disjoint tiles) starts as soon as the pack has read the rank's own tiles. Total work is fixed as N grows:
+"scaling": "strong". value = frame samples * K / max-over-ranks wall time. Every rank count renders with the same sample split
+(terra_amd_set_sample_split, default 8 lanes per pixel: the frame of 8 successive 64-spp calls), so the image does not
+depend on N and a 1/8 share of the frame still fills a GPU.
 
 Also on the JSON line (rank 0):
-  roofline     -- the render kernel's ALGORITHMIC bytes per launch (device work
-                  counters x SURVEY.md 8d's per-unit sizes) / its average launch
-                  duration measured with HIP events on the launch stream, against
-                  the 8 TB/s HBM peak; traffic = measured HBM bytes per launch
-                  from the committed rocprofv3 PMC passes (profiles/), or null.
-  cpu_baseline -- the reference's own CPU renderer (oracle/_ref, prebuilt from its unmodified
-                  sources; kind "reference") on all usable host cores over a bounded crop of the
-                  same workload, with the oracle's rate beside it (port_value); the oracle alone
-                  (kind "port") when the prebuilt reference library is absent. N=1 only.
+  roofline     -- against the resource that binds the render kernel (DESIGN.md "Roofline"):
+                  bound "valu" for scenes staged in LDS: achieved = VALU wave-instructions per second (SQ_INSTS_VALU of the
+                  committed PMC summary profiles/r02_pmc.json / the kernel time measured live with HIP events), peak = 1024
+                  SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; lane_util and the LDS bank-conflict share beside it;
+                  bound "l2_fabric" for scenes read from global memory: achieved = bytes the L2 moved on its fabric side
+                  (FETCH_SIZE/WRITE_SIZE PMC passes, Infinity Cache hits included) per second, peak = the 8 TB/s HBM figure.
+                  algorithmic_* = SURVEY.md 8d's per-unit bytes x the device work counters, kept as its own field.
+  cpu_baseline -- the reference's own CPU renderer (oracle/_ref, prebuilt from its unmodified sources; kind "reference")
+                  on all usable host cores over a bounded sample of the same workload, with the oracle's rate beside it
+                  (port_value); the oracle alone (kind "port") when the prebuilt reference library is absent. N=1 only.
+  workloads    -- (N=1, default invocation) the other BASELINE.json configurations measured the same way in the same run,
+                  each with its own value / ms_per_step / roofline / cpu_baseline. The headline stays configs[1].
 """
 from __future__ import annotations
 
@@ -38,20 +41,75 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-import torch  # before the library: it must bind to the HIP runtime torch loads
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from terra_amd import api, runtime, scenes  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (MI355X_MICROARCH.md "Execution model")
 TILE = 64
+TREE_MODES = {"auto": 2, "reference": 0, "fast": 1}
+INTEGRATORS = {"simple": 0, "direct": 1, "mis": 2}
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_1080p_512spp")
+    ap.add_argument("--integrator", default="", choices=["", "simple", "direct", "mis"], help="override the workload's integrator (the result is then NOT the headline config)")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other configurations)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
+    ap.add_argument("--tree", default="auto", choices=list(TREE_MODES), help="terra_amd_set_tree_mode: auto (2, the library default: leaf-box cull / fast tree when the scene passes the numeric containment check), reference (0: the reference's tree, every traversal decision reproduced), fast (1)")
+    ap.add_argument("--sample-split", type=int, default=8, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
+    ap.add_argument("--check", action="store_true", help="after timing: one sharded+gathered pass on a cleared frame must equal an unsharded pass bit for bit (rank 0)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0 = pick a free one)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# starting the ranks ourselves (no GPU call may precede this: the ranks are CHILD processes, nothing is exec'ed)
+# ------------------------------------------------------------------------------------------------------------------
+
+def launcher_command(args, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            str(Path(__file__).resolve())] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv) -> int:
+    """bench.py --gpus N (N > 1) without a launcher: run the N ranks as a child torch.distributed.run, relay rank 0's JSON line"""
+    port = args.master_port or free_port()
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(launcher_command(args, argv, port), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:] + "\n" + p.stderr[-6000:] + "\n")
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank child exited with code {p.returncode}" + ("" if line else " and printed no result line") + "\n")
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads, bytes, CPU baseline
+# ------------------------------------------------------------------------------------------------------------------
 
 def algorithmic_bytes(st: dict) -> float:
     """64 B per node popped, 36 B per triangle test, 36+60 B per hit,
@@ -59,7 +117,8 @@ def algorithmic_bytes(st: dict) -> float:
     return 64.0 * st["nodes"] + 36.0 * st["tri_tests"] + 96.0 * st["hits"] + 12.0 * st["attr_fetches"] + 44.0 * st["pixels"]
 
 
-def workload(name: str, spp_override):
+def workload(name: str, spp_override=0):
+    from terra_amd import api, scenes
     if name == "cornell_1080p_512spp":
         d = scenes.cornell_box(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "cornell_256_4spp":
@@ -100,210 +159,335 @@ def usable_cores() -> int:
     return n
 
 
-def _time_cpu(lib, prefix, d, cores, seconds_budget, rows_total=None):
+def _time_cpu(lib, prefix, d, cores, seconds_budget, plan=None):
     """one CPU renderer (same C entry-point shape for the compiled reference and the oracle) over a stratified sample of the
-    frame at full spp: up to 8 full-width bands evenly spaced over the height, so that the sample's mix of cheap (background)
-    and expensive (inside the box) pixels is the frame's. Returns (Msamples/s, description, rows used)."""
+    frame: up to 8 full-width bands evenly spaced over the height (so the sample's mix of cheap and expensive pixels is the
+    frame's), at the workload's full spp when the budget allows and at a reduced spp (stated) for the heavy scenes, where a
+    single full-spp row would already exceed it. Returns (Msamples/s, description, plan) -- plan = (rows, spp) for re-use."""
+    import threading
+    from terra_amd import api, scenes
     f = lib.fn(prefix + "render_pixels_mt", None, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 4 + [C.c_uint64, C.c_void_p, C.c_int])
-    scene = scenes.build_scene(lib, d)
-    cam = scenes.camera_of(d)
-    fb = api.Framebuffer(lib, d.width, d.height)
     BANDS = max(1, min(8, cores // 2))
     per_band_threads = max(1, cores // BANDS)
+    cam = scenes.camera_of(d)
+    full_spp = d.spp
 
-    def run(rows):
-        # the bands render concurrently (ctypes drops the GIL), each on its share of the cores, so short bands still use every core
-        import threading
-        per = max(1, rows // BANDS); fb.clear()
-        def one(b):
+    def run(rows, spp):
+        dd = scenes.SceneDesc(**{**d.__dict__, "spp": spp})
+        scene = scenes.build_scene(lib, dd)
+        fb = api.Framebuffer(lib, d.width, d.height)
+        per = max(1, rows // BANDS)
+        def one(b):     # the bands render concurrently (ctypes drops the GIL), each on its share of the cores
             y0 = min(d.height - per, max(0, int((b + 0.5) * d.height / BANDS) - per // 2))
             f(C.byref(cam), scene, C.byref(fb.fb), 0, y0, d.width, per, scenes.FRAME_SEED, None, per_band_threads)
         ths = [threading.Thread(target=one, args=(b,)) for b in range(BANDS)]
         t = time.perf_counter(); [th.start() for th in ths]; [th.join() for th in ths]
-        return per * BANDS, time.perf_counter() - t
+        dt = time.perf_counter() - t
+        fb.destroy(); lib.scene_destroy(scene)
+        return per * BANDS, dt
 
-    if rows_total is None:          # size the sample for ~seconds_budget: a thin pass, then one re-sizing pass if it came out short
-        rows, dt = run(BANDS * 4 * per_band_threads)
-        if dt < 0.6 * seconds_budget:           # (a heavy workload can exhaust the budget with the thin pass alone: then that is the sample)
-            rows_total = int(min(d.height, max(BANDS, rows * seconds_budget / max(dt, 1e-3))))
-            rows, dt = run(rows_total)
-        if dt < 0.6 * seconds_budget and rows < d.height:
-            rows_total = int(min(d.height, rows * seconds_budget / max(dt, 1e-3)))
-            rows, dt = run(rows_total)
+    if plan is None:
+        rows, dt = run(BANDS, 1)                                      # probe: one row per band at 1 spp
+        rate = d.width * rows / max(dt, 1e-4)                          # samples per second (pessimistic: thread start-up included)
+        budget = rate * seconds_budget
+        if budget >= d.width * BANDS * full_spp:                       # full spp fits: as many rows as the budget buys
+            plan = (int(min(d.height, max(BANDS, budget / (d.width * full_spp)))), full_spp)
+        else:                                                          # heavy scene: one row per band, as many of the spp as the budget buys
+            plan = (BANDS, int(max(1, min(full_spp, budget / (d.width * BANDS)))))
+        rows, dt = run(*plan)
+        if dt < 0.5 * seconds_budget and (plan[0] < d.height or plan[1] < full_spp):       # the probe under-estimated: one re-sizing pass
+            k = seconds_budget / max(dt, 1e-3)
+            plan = (plan[0], int(min(full_spp, max(1, plan[1] * k)))) if plan[1] < full_spp else (int(min(d.height, plan[0] * k)), full_spp)
+            rows, dt = run(*plan)
     else:
-        rows, dt = run(rows_total)
-    val = d.width * rows * d.spp / dt / 1e6
-    fb.destroy(); lib.scene_destroy(scene)
-    return val, f"{BANDS} full-width bands of {rows // BANDS} rows evenly spaced over the {d.width}x{d.height} frame ({rows} rows), full {d.spp} spp, {dt:.1f} s", rows
+        rows, dt = run(*plan)
+    spp = plan[1]
+    val = d.width * rows * spp / dt / 1e6
+    what = f"full {full_spp} spp" if spp == full_spp else f"{spp} of the {full_spp} spp"
+    return val, f"{BANDS} full-width bands of {rows // BANDS} rows evenly spaced over the {d.width}x{d.height} frame ({rows} rows), {what}, {dt:.1f} s", plan
 
 
-def cpu_baseline(d: scenes.SceneDesc, seconds_budget: float = 12.0):
+def cpu_baseline(d, seconds_budget: float = 12.0):
     """The reference's own CPU renderer (oracle/_ref/libterra_ref.so: its unmodified sources compiled in the build
     container with per-pixel pinned entropy; kind "reference") when that prebuilt library travelled with the tree, and the
-    oracle (bit-exact CPU restatement; kind "port") -- both on every usable host core, each over a bounded crop."""
-    import subprocess
+    oracle (bit-exact CPU restatement; kind "port") -- both on every usable host core, each over the same bounded sample."""
+    from terra_amd import api
     cores = usable_cores()
     subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
     orc = api.TerraLib(ROOT / "oracle" / "liboracle.so", "orc_")
-    port, port_sample, rows = _time_cpu(orc, "orc_", d, cores, seconds_budget)
+    port, port_sample, plan = _time_cpu(orc, "orc_", d, cores, seconds_budget)
     ref_so = ROOT / "oracle" / "_ref" / "libterra_ref.so"
     if ref_so.exists() and all(o.material.kind in ("diffuse", "phong") for o in d.objects):    # the reference has no GGX/glass preset
-        val, sample, _ = _time_cpu(api.TerraLib(ref_so, "terra_"), "ref_", d, cores, seconds_budget, rows_total=rows)     # the same rows as the oracle's run
-        return {"value": round(val, 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+        val, sample, _ = _time_cpu(api.TerraLib(ref_so, "terra_"), "ref_", d, cores, seconds_budget, plan=plan)     # the same sample as the oracle's run
+        return {"value": round(val, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
                 "sample": sample + f", oracle/_ref/libterra_ref.so (the reference's sources, gcc -O2, one terra_render call per pixel) on {cores} threads",
-                "port_value": round(port, 3), "port_sample": port_sample + f", oracle/liboracle.so on {cores} threads"}
-    return {"value": round(port, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "port_value": round(port, 4), "port_sample": port_sample + f", oracle/liboracle.so on {cores} threads"}
+    return {"value": round(port, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": port_sample + f", oracle/liboracle.so on {cores} threads"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell_1080p_512spp")
-    ap.add_argument("--integrator", default="", choices=["", "simple", "direct", "mis"], help="override the workload's integrator (the result is then NOT the headline config)")
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
-    ap.add_argument("--tree", default="reference", choices=["reference", "fast"], help="reference = the reference's own tree and traversal order (parity mode, the headline); fast = terra_amd_set_tree_mode(1)")
-    ap.add_argument("--sample-split", type=int, default=8, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
-    ap.add_argument("--check", action="store_true", help="after timing: one sharded+gathered pass on a cleared frame must equal an unsharded pass bit for bit (rank 0)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------------
+# roofline
+# ------------------------------------------------------------------------------------------------------------------
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+def source_digest() -> str:
+    """digest of the kernel sources: a PMC record taken on other sources is flagged stale"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "terra_amd" / "csrc").glob("*")):
+        if f.suffix in (".h", ".hip", ".cpp"):
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_key(workload_name, tree, integrator, split, spp_override):
+    return f"{workload_name}|tree={tree}|integrator={integrator}|split={split}" + (f"|spp={spp_override}" if spp_override else "")
+
+
+def roofline(key, st, kernel_ms, lds_resident, world):
+    """st: device work counters per launch; the PMC record (per launch of the render kernel) comes from profiles/r02_pmc.json"""
+    alg = algorithmic_bytes(st)
+    rec = {}
+    f = ROOT / "profiles" / "r02_pmc.json"
+    if f.exists():
+        rec = json.loads(f.read_text()).get(key, {})
+    t = kernel_ms * 1e-3
+    out = {"kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3), "rank0_only": world > 1,
+           "algorithmic_bytes_per_launch": int(alg), "algorithmic_gbs": round(alg / t / 1e9, 1), "pmc_record": key if rec else None}
+    if rec:
+        out["pmc_stale"] = rec.get("source_digest") != source_digest()
+        out["pmc_kernel_ms"] = rec.get("kernel_ms")
+    traffic = rec.get("hbm_bytes_per_launch")
+    if lds_resident:
+        insts = rec.get("SQ_INSTS_VALU")
+        ach = insts / t / 1e9 if insts else None
+        out.update({"bound": "valu", "achieved": round(ach, 1) if ach else None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                    "frac": round(ach / VALU_PEAK_GINST, 4) if ach else None, "traffic": traffic,
+                    "lane_util": rec.get("lane_util"), "lds_bank_conflict_frac": rec.get("lds_bank_conflict_frac"), "valu_insts_per_launch": insts,
+                    "note": "scene staged in LDS: the kernel is bound by VALU issue; achieved = SQ_INSTS_VALU (profiles/r02_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
+                            "A stream of nothing but v_add_f32 sustains 0.96 G/s per SIMD on this part and VOP3 / f64 / integer-multiply streams 0.57 (profiles/r02_measurements/valu_rates.log), so frac ~0.6 is the practical ceiling of this instruction mix; "
+                            "`traffic` is what HBM moved (framebuffer only)"})
+    else:
+        ach = traffic / t / 1e9 if traffic else None
+        out.update({"bound": "l2_fabric", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": traffic, "lane_util": rec.get("lane_util"),
+                    "note": "scene read from global memory (11 MB: L2 / Infinity Cache resident): achieved = bytes the L2 moved on its fabric side per launch (FETCH_SIZE x 2 + WRITE_SIZE PMC passes, "
+                            "Infinity Cache hits included; profiles/r02_pmc.json) / kernel time measured in this run, against the 8 TB/s HBM peak; the kernel is latency bound (dependent 64-B node fetches), not bandwidth bound"})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# measurement
+# ------------------------------------------------------------------------------------------------------------------
+
+class Ctx:
+    pass
+
+
+def setup(args):
+    import torch
     import torch.distributed as dist
+    from terra_amd import runtime
+    c = Ctx()
+    c.world = int(os.environ.get("WORLD_SIZE", "1")); c.rank = int(os.environ.get("RANK", "0")); c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # the multi-rank code path; TERRA_BENCH_DIST1=1 takes it with ONE rank too (shard, pack, RCCL gather, unpack): a self-test of
     # those calls on a 1-GPU box, never a benchmark
-    dist_on = world > 1 or os.environ.get("TERRA_BENCH_DIST1") == "1"
+    c.dist_on = c.world > 1 or os.environ.get("TERRA_BENCH_DIST1") == "1"
     ngpu = torch.cuda.device_count()
     if ngpu < 1:
         raise SystemExit("bench.py needs an MI355X")
-    dev_index = (local_rank % ngpu) if world > 1 else 0        # ranks > GPUs only happens in a gloo rehearsal
+    dev_index = (c.local_rank % ngpu) if c.world > 1 else 0        # ranks > GPUs only happens in a gloo rehearsal
     torch.cuda.set_device(dev_index)
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if c.dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=c.rank, world_size=c.world, device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    dev = torch.device("cuda", dev_index)
-    via_host = dist_on and args.dist_backend != "nccl"
-
-    lib = runtime.load()
-    if lib.device_count() <= 0:
+            dist.init_process_group(args.dist_backend, rank=c.rank, world_size=c.world)
+    c.dev = torch.device("cuda", dev_index)
+    c.via_host = c.dist_on and args.dist_backend != "nccl"
+    c.dist = dist; c.torch = torch
+    c.lib = runtime.load()
+    if c.lib.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: " + runtime.last_error())
-    runtime.check(lib.set_device(dev.index), "terra_amd_set_device")
+    runtime.check(c.lib.set_device(c.dev.index), "terra_amd_set_device")
+    return c
 
-    d = workload(args.workload, args.spp)
-    if args.integrator:
-        d.integrator = {"simple": api.kTerraIntegratorSimple, "direct": api.kTerraIntegratorDirect, "mis": api.kTerraIntegratorDirectMis}[args.integrator]
-    scene = scenes.build_scene(lib, d, tree_mode=1 if args.tree == "fast" else 0)
+
+def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
+    """K timed steps of workload d; returns the measurement (rank 0) incl. per-launch work counters"""
+    from terra_amd import runtime, scenes
+    torch, dist, lib, dev = c.torch, c.dist, c.lib, c.dev
+    world, rank = c.world, c.rank
+    lib.clear_error()
+    scene = scenes.build_scene(lib, d, tree_mode=TREE_MODES[tree])
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
-    runtime.check(lib.set_sample_split(scene, args.sample_split), "terra_amd_set_sample_split")
+    runtime.check(lib.set_sample_split(scene, split), "terra_amd_set_sample_split")
+    ti = runtime.TraversalInfo(); runtime.check(lib.traversal_info(scene, C.byref(ti)))
+    info = runtime.SceneInfo(); runtime.check(lib.scene_info(scene, C.byref(info)))
     cam = scenes.camera_of(d)
     fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
-    n_packed = runtime.packed_floats_per_rank(d.width, d.height, TILE, world)
-    packed = torch.zeros(n_packed, dtype=torch.float32, device=dev) if dist_on else None
-    gather_bufs = [torch.zeros(n_packed, dtype=torch.float32, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    W, H = d.width, d.height
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev) if c.dist_on else None
+    n_packed = runtime.packed_floats_per_rank(W, H, TILE, world)
+    packed = torch.zeros(n_packed, dtype=torch.float32, device=dev) if c.dist_on else None
+    pool = [torch.zeros(n_packed, dtype=torch.float32, device="cpu" if c.via_host else dev) for _ in range(world)] if (c.dist_on and rank == 0) else []
+    stage = torch.zeros(n_packed, dtype=torch.float32, device=dev) if (c.via_host and rank == 0) else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    ev_packed = torch.cuda.Event()
+
+    def fb_pack(r):          # on the side stream
+        runtime.check(lib.pack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, r, world, packed.data_ptr(), side.cuda_stream), "pack")
+        ev_packed.record(side)
+        return packed.cpu() if c.via_host else packed
+
+    def fb_unpack(src, buf):
+        if c.via_host:
+            stage.copy_(buf); buf = stage
+        runtime.check(lib.unpack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, src, world, buf.data_ptr(), side.cuda_stream), "unpack")
+
+    cursor = [0]
+    def make_buffer(n):      # the gather's receive buffers, pre-allocated (one per rank)
+        b = pool[cursor[0] % len(pool)]; cursor[0] += 1
+        return b
 
     def step(i=None):
         if i is not None:
-            ev[i][0].record()
-        if not dist_on:
-            runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, stream), "render")
+            ev[i][0].record(main)
+        if not c.dist_on:
+            runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, None, main.cuda_stream), "render")
         else:
-            runtime.check(lib.render_device_sharded(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, None, stream), "render")
+            runtime.check(lib.render_device_sharded(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, rank, world, None, main.cuda_stream), "render")
         if i is not None:
-            ev[i][1].record()
-        if dist_on:
-            runtime.check(lib.pack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, rank, world, packed.data_ptr(), stream), "pack")
-            if via_host:
-                torch.cuda.synchronize(dev)
-                hb = [torch.zeros(n_packed, dtype=torch.float32) for _ in range(world)] if rank == 0 else None
-                dist.gather(packed.cpu(), gather_list=hb, dst=0)
-                if rank == 0:
-                    for src in range(1, world):
-                        gather_bufs[src].copy_(hb[src])
-            else:
-                dist.gather(packed, gather_list=gather_bufs, dst=0)
-            if rank == 0:
-                for src in range(1, world):
-                    runtime.check(lib.unpack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, TILE, src, world, gather_bufs[src].data_ptr(), stream), "unpack")
+            ev[i][1].record(main)
+        if c.dist_on:
+            side.wait_stream(main)                   # the pack reads what this render wrote
+            with torch.cuda.stream(side):
+                runtime.gather_frame(fb_pack, fb_unpack, W, H, TILE, rank, world, dist, make_buffer)
+            main.wait_event(ev_packed)               # the next render may overwrite the rank's own tiles once they are packed; the gather and
+                                                     # rank 0's unpack (other ranks' tiles) overlap with it
 
     def fence():
-        if dist_on:
+        if c.dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    if prewarm_rect:          # loads the kernel's code object with a small rectangle when a full warm-up step would take seconds
+        x, y, w, h = prewarm_rect
+        runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, x, y, w, h, None, main.cuda_stream), "render")
+        fence(); fb.clear()
+    for _ in range(warmup):
         step()
     fence()
     runtime.check(lib.reset_stats(scene))
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if dist_on:
+    if c.dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
+    launches = max(1, st["launches"])
 
-    check = None
-    if args.check:
+    ok = None
+    if check:
         fb.clear(); fence(); step(); fence()
         if rank == 0:
-            ref_fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
-            runtime.check(lib.render_device(C.byref(cam), scene, ref_fb.pixels.data_ptr(), ref_fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, stream), "render")
+            ref_fb = runtime.DeviceFramebuffer(W, H, device=dev)
+            runtime.check(lib.render_device(C.byref(cam), scene, ref_fb.pixels.data_ptr(), ref_fb.results.data_ptr(), W, H, 0, 0, W, H, None, main.cuda_stream), "render")
             torch.cuda.synchronize(dev)
-            check = bool(torch.equal(ref_fb.pixels.view(torch.int32), fb.pixels.view(torch.int32)) and torch.equal(ref_fb.results, fb.results))
-    st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+            ok = bool(torch.equal(ref_fb.pixels.view(torch.int32), fb.pixels.view(torch.int32)) and torch.equal(ref_fb.results, fb.results))
+            del ref_fb
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "check": ok,
+           "per_launch": {k: v // launches for k, v in st.items() if k != "launches"},
+           "traversal": {"fast_tree": bool(ti.fast_tree), "leaf_cull": bool(ti.leaf_cull), "note": ti.note.decode()},
+           "lds_resident": bool(ti.lds_resident),
+           "triangles": info.triangles}
+    lib.scene_destroy(scene)
+    del fb
+    return out
+
+
+def result_block(d, name, tree, split, steps, warmup, world, m, spp_override, integrator_name):
     frame_samples = d.width * d.height * d.spp
-    value = frame_samples * args.steps / elapsed / 1e6
+    st = m["per_launch"] or {}
+    trav = "fast tree" if m["traversal"]["fast_tree"] else ("reference tree + leaf-box cull" if m["traversal"]["leaf_cull"] else "reference tree, replica traversal")
+    out = {"value": round(frame_samples * steps / m["elapsed"] / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(m["elapsed"] / steps * 1e3, 3),
+           "config": {"workload": name, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces, "integrator": integrator_name,
+                      "triangles": d.triangle_count, "tree": tree, "traversal": trav, "tile": TILE, "sample_split": split,
+                      "parallelism": f"tiles%{world}" if world > 1 else "single"}}
+    if st:
+        out["mrays_per_s"] = round(st["rays"] * world / (m["kernel_ms"] * 1e-3) / 1e6, 1)
+        out["roofline"] = roofline(pmc_key(name, tree, integrator_name, split, spp_override), st, m["kernel_ms"], m["lds_resident"], world)
+        out["counters_per_launch"] = st
+    return out
+
+
+EXTRA_WORKLOADS = [
+    # (workload, tree, integrator, split, steps, warmup, prewarm rectangle, CPU seconds)
+    ("hall_1080p_256spp", "auto", "simple", 1, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
+    ("hall_1080p_256spp", "reference", "simple", 1, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (6 s per step)
+    ("spheres_1080p_1024spp", "auto", "simple", 8, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
+    ("cornell_1080p_512spp_direct", "auto", "direct", 8, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
+]
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
+    import torch  # noqa: F401  before the library: it must bind to the HIP runtime torch loads
+    c = setup(args)
+    world, rank = c.world, c.rank
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+
+    d = workload(args.workload, args.spp)
+    if args.integrator:
+        d.integrator = INTEGRATORS[args.integrator]
+    integ_name = {0: "simple", 1: "direct", 2: "mis"}.get(d.integrator, str(d.integrator))
+    m = measure(c, d, args.tree, args.sample_split, args.steps, args.warmup, check=args.check)
 
     if rank == 0:
-        alg = algorithmic_bytes(st) / max(1, st["launches"])
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "roofline_traffic.json"
-        if tf.exists() and world == 1 and not args.spp:
-            rec = json.loads(tf.read_text()).get(args.workload + ("" if args.tree == "reference" else ":" + args.tree), {})
-            if rec.get("sample_split", 1) == args.sample_split and not args.integrator:      # the PMC passes were taken on this configuration
-                traffic = rec.get("hbm_bytes_per_launch")
-        out = {
-            "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces,
-                       "integrator": {0: "simple", 1: "direct", 2: "mis"}.get(d.integrator, str(d.integrator)),
-                       "triangles": d.triangle_count, "tree": args.tree, "tile": TILE, "sample_split": args.sample_split, "parallelism": f"tiles%{world}" if world > 1 else "single"},
-            "mrays_per_s": round(st["rays"] / max(1, st["launches"]) * (1 if world == 1 else world) / (kernel_ms * 1e-3) / 1e6, 1),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg), "rank0_only": world > 1,
-                         "note": "achieved = algorithmic bytes (SURVEY 8d) / kernel time; it can exceed the HBM peak because a scene that fits is served from LDS (or L2 / Infinity Cache): `traffic` is what HBM actually moved"},
-            "counters_per_launch": {k: v // max(1, st["launches"]) for k, v in st.items() if k != "launches"},
-        }
-        if check is not None:
-            out["sharded_equals_unsharded"] = check
-        if dist_on:
+        blk = result_block(d, args.workload, args.tree, args.sample_split, args.steps, args.warmup, world, m, args.spp, integ_name)
+        out = {"metric": "Msamples/s", "value": blk["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": blk["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": blk["config"]}
+        for k in ("mrays_per_s", "roofline", "counters_per_launch"):
+            if k in blk:
+                out[k] = blk[k]
+        out["traversal_note"] = m["traversal"]["note"]
+        if m["check"] is not None:
+            out["sharded_equals_unsharded"] = m["check"]
+        if c.dist_on:
             out["dist_backend"] = args.dist_backend
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
+        headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == 8
+        if world == 1 and not c.dist_on and headline and not args.no_workloads:
+            extra = []
+            for name, tree, integ, split, steps, warmup, prewarm, cpu_s in EXTRA_WORKLOADS:
+                dw = workload(name)
+                mw = measure(c, dw, tree, split, steps, warmup, prewarm_rect=prewarm)
+                b = result_block(dw, name, tree, split, steps, warmup, 1, mw, 0, integ)
+                if name.startswith("spheres"):
+                    b["parity"] = "unpinned: the GGX and glass presets are this repo's definitions (the reference's are dead code, src/TerraPresets.c:298-465)"
+                if cpu_s and not args.no_cpu_baseline:
+                    b["cpu_baseline"] = cpu_baseline(dw, cpu_s)
+                extra.append(b)
+            out["workloads"] = extra
         print(json.dumps(out), flush=True)
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+    if c.dist_on:
+        c.dist.barrier()
+        c.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -47,14 +47,31 @@ int  terra_amd_get_device ( void );
 void     terra_amd_set_frame_seed ( HTerraScene scene, uint64_t seed );
 uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
 
-/* Accelerator used by subsequent commits. 0 (default) = the reference's own tree (X-only sweep SAH,
-   src/TerraBVH.c:79-244) traversed in the reference's order: the parity mode. 1 = "fast tree": a
-   3-axis binned-SAH BVH2 over the same triangles with ordered, culled traversal; ties in depth are
-   resolved by the reference tree's leaf visit order, so it selects the same triangle as mode 0
-   (DESIGN.md "Fast tree"). 2 = automatic: the reference tree when the whole scene is staged in
-   LDS (there it is the faster of the two), the fast tree otherwise. Takes effect at the next terra_scene_commit(). */
+/* Traversal policy of subsequent commits (replaces src/TerraBVH.c:128-310 on the device).
+   0 = replica: the reference's own tree (X-only sweep SAH, src/TerraBVH.c:79-244) traversed decision by decision as
+       terra_bvh_traverse does (every leaf met is triangle-tested, nothing is culled).
+   1 = fast tree, unconditionally: a 3-axis binned-SAH BVH2 over the same triangles with ordered, culled traversal; ties in
+       depth are resolved by the reference tree's leaf visit order, so it selects the same triangle as mode 0 (DESIGN.md
+       "Fast tree").
+   2 = automatic (DEFAULT): at commit the scene is checked numerically (every coordinate within +-13 units, where the reference's
+       1e-4 box margin provably exceeds the rounding error of the slab and triangle tests; every leaf / fast-tree box contains what
+       it was built around). Scenes that pass run the reference tree with the leaf-box cull (a leaf's triangle is tested only
+       if the ray passes that leaf's own box) when they fit in LDS, and the fast tree otherwise; scenes that fail -- and calls
+       whose camera lies outside the checked range -- run as mode 0. All three produce the reference's image bit for bit; only
+       mode 0 also reproduces its work counters. terra_amd_traversal_info() reports the decision and the reason.
+   Takes effect at the next terra_scene_commit(). */
 int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
 int  terra_amd_get_tree_mode ( HTerraScene scene );
+typedef struct {
+    int   tree_mode;                /* as set */
+    int   fast_tree;                /* 1: the fast tree is used */
+    int   leaf_cull;                /* 1: reference tree with the leaf-box cull */
+    int   lds_resident;             /* 1: the whole scene (nodes, triangles, vertex properties) is staged in LDS by every block */
+    float max_coordinate;           /* largest |vertex coordinate| of the committed scene */
+    float max_coordinate_allowed;   /* limit of the numeric containment check */
+    char  note[192];                /* the reason, in words */
+} TerraAmdTraversalInfo;
+int  terra_amd_traversal_info ( HTerraScene scene, TerraAmdTraversalInfo* out );
 
 /* Sample split: how many lanes share one pixel. With split = S (1, 2, 4, 8 or 16; default 1) a render call of
    spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random
@@ -93,6 +110,7 @@ typedef struct {
     uint64_t attr_fetches;  /* (attributes_count + 1) summed over hits */
     uint64_t pixels;        /* pixels written */
     uint64_t launches;      /* render kernel launches */
+    uint64_t tri_culled;    /* leaves met whose triangle test the leaf-box cull skipped (counted by fully counting launches only: rand_calls requested) */
 } TerraAmdStats;
 int terra_amd_get_stats ( HTerraScene scene, TerraAmdStats* out );
 int terra_amd_reset_stats ( HTerraScene scene );

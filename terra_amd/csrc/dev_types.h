@@ -115,7 +115,7 @@ struct DevScene {
 #define TERRA_KIND_TEX 32
 
 // indices into the device counter array (uint64 each); mirrors TerraAmdStats
-enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrFaults,
+enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrFaults, kCtrTriCulled,
        kCtrDbg0, kCtrDbgLast = kCtrDbg0 + 15, kCtrCount };   // kCtrFaults: only written by TERRA_CHECK_BOUNDS builds; kCtrDbg*: only by TERRA_PHASE_STATS builds (lane-occupancy study)
 
 struct DevRenderParams {
@@ -156,4 +156,5 @@ struct DevRenderParams {
     uint32_t lean_attr_per_hit;
     int32_t  count_level;           // 1 lean, 2 full (see trace_device.h randf)
     uint32_t bsdf_kinds;            // mask of DevBsdfKind present in the scene (bit k = kind k)
+    uint32_t leaf_cull;             // 1: skip the triangle test of a leaf child whose box the ray misses (Tracer::cull); host decides per call
 };

@@ -53,7 +53,7 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t
 #ifndef TERRA_CHECK_SHRINK
 #define TERRA_CHECK_SHRINK 0
 #endif
-TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
+TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris, bool cull ) {
     const int tid = threadIdx.x;
     Tracer T;
     T.sc = sc;
@@ -64,6 +64,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.leaf_cap = ( int ) leaf_cap;
     T.stack_cap = ( int ) stack_depth - TERRA_CHECK_SHRINK;      // TERRA_CHECK_SHRINK > 0: positive control of the bounds check
     T.faults = nullptr;
+    T.cull = cull;
     float4* stage = lds + ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 64;
     float4* ln = stage;
     float4* lt = ln + 4 * lds_nodes;
@@ -209,7 +210,7 @@ template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
-    Tracer T0 = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
+    Tracer T0 = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0 );
     T0.faults = p.counters + kCtrFaults;
     const Tracer T = T0;
 
@@ -489,6 +490,11 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         if ( COUNT == 2 && p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
     }
     if ( COUNT ) wave_flush_counters<COUNT> ( c, p.counters, p.lean_attr_per_hit );
+    if ( COUNT == 2 && p.leaf_cull ) {
+        unsigned long long x = c.tri_culled;
+        for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
+        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &p.counters[kCtrTriCulled], x );
+    }
 #if TERRA_PHASE_STATS
     for ( int k = 0; k < 16; ++k ) {
         unsigned long long x = c.ps[k];

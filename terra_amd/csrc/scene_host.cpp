@@ -220,6 +220,7 @@ extern "C" void terra_framebuffer_destroy ( TerraFramebuffer* fb ) {
 // ------------------------------------------------------------------------------
 struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 
+#define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
 struct Scene {
     TerraSceneOptions opts, new_opts;
     TerraObject* objects = nullptr; size_t objects_pop = 0, objects_cap = 0;
@@ -236,8 +237,14 @@ struct Scene {
     std::atomic<uint64_t> launches { 0 }, stat_pixels { 0 }, stat_samples { 0 };     // terra_render() is called from several threads at once
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
-    int tree_mode = 0;                  // 0 = the reference's tree (parity default), 1 = fast tree, 2 = fast tree unless the scene is LDS-resident
+    // traversal policy (terra_amd_set_tree_mode): 0 = replica: the reference's tree, every traversal decision reproduced; 1 = fast tree, unconditionally;
+    // 2 = automatic (default): scenes that pass the numeric containment check of verify_containment() run the reference tree with the
+    // leaf-box cull when they are LDS-resident and the fast tree otherwise; scenes that fail it run as mode 0 (the reason is kept in tree_note)
+    int tree_mode = 2;
     bool use_fast = false;              // what the last upload decided
+    bool cull_ok = false;               // leaf-box cull allowed for this scene (subject to the per-call camera check)
+    float coord_max = 0.f;              // largest |coordinate| of any vertex
+    std::string tree_note;              // why the automatic mode chose what it chose
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
@@ -277,6 +284,17 @@ extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
     return 0;
 }
 extern "C" int terra_amd_get_tree_mode ( HTerraScene h ) { return S ( h )->tree_mode; }
+extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* out ) {
+    Scene* s = S ( h );
+    if ( !out ) return fail ( kTerraAmdErrBadArgument, "null output" );
+    memset ( out, 0, sizeof *out );
+    if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "scene not committed" );
+    out->tree_mode = s->tree_mode; out->fast_tree = s->use_fast ? 1 : 0; out->leaf_cull = ( s->cull_ok && !s->use_fast ) ? 1 : 0;
+    out->lds_resident = ( !s->use_fast && terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), s->dev.n_tris, s->max_stack ) ) ? 1 : 0;
+    out->max_coordinate = s->coord_max; out->max_coordinate_allowed = TERRA_CULL_MAX_COORD;
+    snprintf ( out->note, sizeof out->note, "%s", s->tree_note.c_str() );
+    return 0;
+}
 extern "C" int terra_amd_set_sample_split ( HTerraScene h, int split ) {
     if ( split != 0 && split != 1 && split != 2 && split != 4 && split != 8 && split != 16 ) return fail ( kTerraAmdErrBadArgument, "sample split %d: must be 0 (automatic), 1, 2, 4, 8 or 16", split );
     S ( h )->sample_split = ( uint32_t ) split;
@@ -328,6 +346,83 @@ static bool is_diffuse ( const TerraBSDF& b ) { return b.sample == terra_bsdf_di
 static bool is_ggx ( const TerraBSDF& b ) { return b.sample == terra_bsdf_ggx_sample && b.pdf == terra_bsdf_ggx_pdf && b.eval == terra_bsdf_ggx_eval; }
 static bool is_glass ( const TerraBSDF& b ) { return b.sample == terra_bsdf_glass_sample && b.pdf == terra_bsdf_glass_pdf && b.eval == terra_bsdf_glass_eval; }
 static bool is_phong ( const TerraBSDF& b ) { return b.sample == terra_bsdf_phong_sample && b.pdf == terra_bsdf_phong_pdf && b.eval == terra_bsdf_phong_eval; }
+
+// ---- numeric containment check behind the automatic traversal mode ---------------------------------------------------------
+// Both shortcuts of mode 2 -- skipping the triangle test of a leaf whose box the ray misses, and the fast tree's ordered, culled
+// traversal -- return the reference's closest hit provided that every triangle a ray HITS (watertight test, src/TerraGeometry.c:159-260)
+// lies inside each box that was built around it AS THE SLAB TEST SEES IT (src/Terra.c:851-878). The boxes are the triangle's extent
+// grown by 1e-4 on every side (src/Terra.c:982-996) or unions of such boxes, so geometrically that is always true; numerically it
+// needs the rounding errors of both tests to stay below the 1e-4 margin. With u = 2^-24 and D = the largest distance between a ray
+// origin and a vertex: translating and shearing the vertices perturbs them by <= 4 u D per coordinate, the sign of an edge function
+// can be wrong only within ~2 u D of the edge, the slab test's t values carry <= 3 roundings (<= ~6 u D in position), the box itself
+// is rounded by <= u R: together < 16 u D, D <= 2 sqrt(3) R for origins and vertices inside [-R, R]^3, i.e. < 56 u R.
+// The check demands 128 u R <= 1e-4 (a factor 2.3 beyond that estimate): R <= 13.1 scene units, for the vertices (at commit) and for
+// the camera position (per call). Scenes or cameras outside that range run in replica mode. tools/fuzz_vs_oracle.py scales scenes
+// through and beyond the limit (FUZZ_SCALE) to exercise both sides.
+static bool coords_within_margin ( const float* v, size_t n ) {
+    for ( size_t i = 0; i < n; ++i ) if ( ! ( fabsf ( v[i] ) <= TERRA_CULL_MAX_COORD ) ) return false;      // also false for NaN / inf
+    return true;
+}
+// every leaf child box of the reference tree contains its triangle's extent grown by (almost) 1e-4
+static bool verify_reference_leaf_boxes ( const Scene* s, std::string& why ) {
+    for ( size_t k = 0; k < s->nodes.size(); ++k ) for ( int c = 0; c < 2; ++c ) {
+        const HostNode& h = s->nodes[k];
+        if ( h.type[c] != 1 ) continue;
+        const uint32_t obj = ( uint32_t ) h.index[c] & 0xffu, tri = ( uint32_t ) h.index[c] >> 8;
+        if ( obj >= s->objects_pop || tri >= s->objects[obj].triangles_count ) { why = "leaf references a missing triangle"; return false; }
+        const TerraTriangle& t = s->objects[obj].triangles[tri];
+        const float* a = &t.a.x; const float* b = &t.b.x; const float* cc = &t.c.x;
+        const float* lo = &h.aabb[c].min.x; const float* hi = &h.aabb[c].max.x;
+        for ( int ax = 0; ax < 3; ++ax ) {
+            const float mn = std::min ( a[ax], std::min ( b[ax], cc[ax] ) ), mx = std::max ( a[ax], std::max ( b[ax], cc[ax] ) );
+            if ( ! ( ( double ) lo[ax] <= ( double ) mn - 0.9e-4 && ( double ) hi[ax] >= ( double ) mx + 0.9e-4 ) ) { why = "a leaf box of the reference tree does not contain its triangle's 1e-4 margin"; return false; }
+        }
+    }
+    return true;
+}
+// every child box of the fast tree contains the boxes of all triangles below it (what its culling relies on)
+static bool verify_fast_tree ( const std::vector<DevNode>& nodes, const std::vector<fastbvh::Prim>& prims_in_leaf_order, std::string& why ) {
+    if ( nodes.empty() ) return true;
+    struct Item { uint32_t node; TerraAABB bound[2]; int stage; };
+    // iterative post-order: compute the union of triangle boxes below each child and compare with the stored box
+    std::vector<TerraAABB> below ( nodes.size() * 2 );
+    std::vector<std::pair<uint32_t, int>> st; st.push_back ( { 0u, 0 } );
+    auto contains = [] ( const float* lo, const float* hi, const TerraAABB & b ) {
+        return lo[0] <= b.min.x && lo[1] <= b.min.y && lo[2] <= b.min.z && hi[0] >= b.max.x && hi[1] >= b.max.y && hi[2] >= b.max.z;
+    };
+    auto unite = [] ( TerraAABB & a, const TerraAABB & b ) {
+        a.min.x = std::min ( a.min.x, b.min.x ); a.min.y = std::min ( a.min.y, b.min.y ); a.min.z = std::min ( a.min.z, b.min.z );
+        a.max.x = std::max ( a.max.x, b.max.x ); a.max.y = std::max ( a.max.y, b.max.y ); a.max.z = std::max ( a.max.z, b.max.z );
+    };
+    while ( !st.empty() ) {
+        auto [ni, stage] = st.back(); st.pop_back();
+        const DevNode& n = nodes[ni];
+        if ( stage == 0 ) {
+            st.push_back ( { ni, 1 } );
+            for ( int c = 0; c < 2; ++c ) if ( n.child[c] != DEV_CHILD_EMPTY && ! ( n.child[c] & DEV_CHILD_LEAF ) ) {
+                if ( n.child[c] >= nodes.size() ) { why = "fast tree: child index out of range"; return false; }
+                st.push_back ( { n.child[c], 0 } );
+            }
+            continue;
+        }
+        for ( int c = 0; c < 2; ++c ) {
+            TerraAABB u = bvh::empty_box();
+            if ( n.child[c] == DEV_CHILD_EMPTY ) { below[2 * ni + c] = u; continue; }
+            if ( n.child[c] & DEV_CHILD_LEAF ) {
+                const uint32_t first = n.child[c] & 0x07ffffffu, cnt = ( ( n.child[c] >> 27 ) & 0xfu ) + 1;
+                if ( ( size_t ) first + cnt > prims_in_leaf_order.size() ) { why = "fast tree: leaf range out of range"; return false; }
+                for ( uint32_t j = 0; j < cnt; ++j ) unite ( u, prims_in_leaf_order[first + j].box );
+            } else {
+                const uint32_t ch = n.child[c];
+                unite ( u, below[2 * ch] ); unite ( u, below[2 * ch + 1] );
+            }
+            below[2 * ni + c] = u;
+            const float* lo = c == 0 ? n.min0 : n.min1; const float* hi = c == 0 ? n.max0 : n.max1;
+            if ( !contains ( lo, hi, u ) ) { why = "fast tree: a child box does not contain the triangle boxes below it"; return false; }
+        }
+    }
+    return true;
+}
 
 // validates that every material can run on the device and uploads the flattened scene
 static int upload_scene ( Scene* s ) {
@@ -445,7 +540,22 @@ static int upload_scene ( Scene* s ) {
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
     std::vector<DevNode> fnodes; std::vector<DevTri> ftris;
     s->fast_nodes = 0; s->fast_max_stack = 1;
-    s->use_fast = s->tree_mode == 1 || ( s->tree_mode == 2 && !terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack ) );
+    // traversal policy (see Scene::tree_mode and the containment check above)
+    s->coord_max = 0.f; s->cull_ok = false; s->tree_note.clear();
+    bool margin_ok = true;
+    for ( size_t j = 0; j < nobj && margin_ok; ++j ) margin_ok = coords_within_margin ( &s->objects[j].triangles[0].a.x, s->objects[j].triangles_count * 9 );
+    for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count * 9; ++i ) { float v = fabsf ( ( &s->objects[j].triangles[0].a.x ) [i] ); if ( v > s->coord_max ) s->coord_max = v; }
+    const bool resident = terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack );
+    bool auto_ok = false;
+    if ( s->tree_mode == 2 ) {
+        std::string why;
+        if ( ntri < 2 ) s->tree_note = "fewer than 2 triangles: replica traversal";
+        else if ( !margin_ok ) { char b[160]; snprintf ( b, sizeof b, "a vertex coordinate exceeds %.1f (largest %.6g): the 1e-4 box margin is not provably above rounding error, replica traversal", ( double ) TERRA_CULL_MAX_COORD, ( double ) s->coord_max ); s->tree_note = b; }
+        else if ( !verify_reference_leaf_boxes ( s, why ) ) s->tree_note = why + ": replica traversal";
+        else auto_ok = true;
+    } else s->tree_note = s->tree_mode == 0 ? "replica traversal requested" : "fast tree requested";
+    s->cull_ok = auto_ok;
+    s->use_fast = s->tree_mode == 1 || ( auto_ok && !resident );
     if ( s->use_fast ) {
         // rank of every soup triangle in the reference traversal's leaf visit order (all boxes hit)
         std::vector<uint32_t> rank ( ntri ? ntri : 1, 0 );
@@ -466,12 +576,18 @@ static int upload_scene ( Scene* s ) {
             q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
             q.soup = ( uint32_t ) ( s->first_tri[j] + i );
         }
-        fastbvh::Built built = fastbvh::build ( prims );
+        fastbvh::Built built = fastbvh::build ( prims );        // (reorders prims into leaf order)
+        std::string why;
+        if ( s->tree_mode == 2 && !verify_fast_tree ( built.nodes, prims, why ) ) {       // cannot happen with this builder (plain unions); checked because the culling relies on it
+            s->use_fast = false; s->tree_note = why + ": reference tree";
+            built.nodes.clear(); built.order.clear();
+        }
         fnodes.swap ( built.nodes );
         ftris.resize ( ntri ? ntri : 1 );
         for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
         s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
     }
+    if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? "containment verified: fast tree (scene is not LDS-resident)" : "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
     // one blob, 256-byte aligned sections
     auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
@@ -585,9 +701,9 @@ extern "C" int terra_amd_get_stats ( HTerraScene h, TerraAmdStats* out ) {
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( c, s->d_counters, sizeof c, hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
     out->rays = c[kCtrRays]; out->nodes = c[kCtrNodes]; out->tri_tests = c[kCtrTriTests]; out->hits = c[kCtrHits];
-    out->rand_calls = c[kCtrRandCalls]; out->attr_fetches = c[kCtrAttrFetches];
+    out->rand_calls = c[kCtrRandCalls]; out->attr_fetches = c[kCtrAttrFetches]; out->tri_culled = c[kCtrTriCulled];
     // derived exactly on the host (see Counters in trace_device.h)
-    out->box_tests = s->dev.n_tris >= 2 ? 2 * out->nodes - out->tri_tests : 0;
+    out->box_tests = s->dev.n_tris >= 2 ? ( s->cull_ok && !s->use_fast ? 2 * out->nodes : 2 * out->nodes - out->tri_tests ) : 0;      // with the leaf-box cull every child's slab test is used
     out->samples = s->stat_samples; out->pixels = s->stat_pixels; out->launches = s->launches;
     return 0;
 }
@@ -662,7 +778,10 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.frame_seed = s->frame_seed;
     p.counters = s->d_counters;
     terra_plan_lds ( p );
-    if ( s->use_fast && s->dev.fast_nodes ) { p.lds_mode = 2; p.lds_nodes = 0; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) s->dev.fast_max_stack; }
+    // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
+    const bool cam_ok = coords_within_margin ( p.cam_pos, 3 );
+    if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) { p.lds_mode = 2; p.lds_nodes = 0; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) s->dev.fast_max_stack; }
+    p.leaf_cull = ( s->cull_ok && cam_ok && p.lds_mode != 2 ) ? 1u : 0u;
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;
     p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;

@@ -80,12 +80,13 @@ struct RayState { float shearx, sheary, scalez; int ix, iy, iz; };
 #endif
 struct Counters {
     uint32_t rays, nodes, tri_tests, hits, rand_calls, attr_fetches;
+    uint32_t tri_culled;     // leaves met whose triangle test was skipped (Tracer::cull); counted at COUNT level 2 only
 #if TERRA_PHASE_STATS
     uint32_t ps[16];
 #endif
 };
 TD Counters counters_zero() {
-    Counters c; c.rays = c.nodes = c.tri_tests = c.hits = c.rand_calls = c.attr_fetches = 0;
+    Counters c; c.rays = c.nodes = c.tri_tests = c.hits = c.rand_calls = c.attr_fetches = c.tri_culled = 0;
 #if TERRA_PHASE_STATS
     for ( int i = 0; i < 16; ++i ) c.ps[i] = 0;
 #endif
@@ -227,6 +228,11 @@ struct Tracer {
     int           leaf_cap;    // entries in the leaf list (>= 2)
     int           stack_cap;   // entries in the stack column (TERRA_CHECK_BOUNDS builds verify every push against it)
     unsigned long long* faults;
+    // leaf-box cull (DESIGN.md "Leaf-box cull"): a leaf child's triangle is tested only if the ray passes the slab test of
+    // that child's box -- the box the node already carries and the node step already tests. The reference tests the triangle
+    // unconditionally (src/TerraBVH.c:284-300); the closest hit is the same whenever a triangle the ray hits lies inside its
+    // own +-1e-4 box as the slab test sees it, which the host verifies numerically at commit (terra_cull_margin_ok).
+    bool cull;
 };
 
 // -----------------------------------------------------------------------------
@@ -335,8 +341,10 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
             bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
             if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
             if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
-            if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
-            if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
+            const bool met0 = leaf0 && child0 != DEV_CHILD_EMPTY, met1 = leaf1 && child1 != DEV_CHILD_EMPTY;
+            if ( met0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
+            if ( met1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
+            if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( met0 && !hit0 ) + ( uint32_t ) ( met1 && !hit1 );
         }
         for ( int i = 0; i < nleaf; ++i ) {
             PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
@@ -478,8 +486,10 @@ TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 
                 bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
                 if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
                 if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
-                if ( leaf0 && child0 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
-                if ( leaf1 && child1 != DEV_CHILD_EMPTY ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
+                const bool met0 = leaf0 && child0 != DEV_CHILD_EMPTY, met1 = leaf1 && child1 != DEV_CHILD_EMPTY;
+                if ( met0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
+                if ( met1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
+                if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( met0 && !hit0 ) + ( uint32_t ) ( met1 && !hit1 );
             }
         }
         for ( int i = 0; i < nleaf; ++i ) {         // lanes that are not traversing hold nleaf == 0

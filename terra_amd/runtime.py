@@ -29,10 +29,14 @@ class TerraAmdError(RuntimeError):
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "box_tests", "tri_tests", "hits", "samples", "rand_calls", "attr_fetches", "pixels", "launches")]
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "box_tests", "tri_tests", "hits", "samples", "rand_calls", "attr_fetches", "pixels", "launches", "tri_culled")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class TraversalInfo(C.Structure):
+    _fields_ = [("tree_mode", C.c_int), ("fast_tree", C.c_int), ("leaf_cull", C.c_int), ("lds_resident", C.c_int), ("max_coordinate", C.c_float), ("max_coordinate_allowed", C.c_float), ("note", C.c_char * 192)]
 
 
 class SceneInfo(C.Structure):
@@ -52,6 +56,7 @@ _EXTRA = {
     "terra_amd_get_frame_seed": (C.c_uint64, [C.c_void_p]),
     "terra_amd_set_tree_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_tree_mode": (C.c_int, [C.c_void_p]),
+    "terra_amd_traversal_info": (C.c_int, [C.c_void_p, C.POINTER(TraversalInfo)]),
     "terra_amd_set_sample_split": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_sample_split": (C.c_int, [C.c_void_p]),
     "terra_amd_set_environment_lighting": (C.c_int, [C.c_void_p, C.c_int]),

@@ -450,11 +450,12 @@ def apply_options(lib: api.TerraLib, scene, d: SceneDesc) -> None:
     o.gamma = d.gamma
 
 
-def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode: int = 0):
+def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode=None):
     """Returns a committed HTerraScene (c_void_p value) owned by `lib`.
-    tree_mode 1 selects the product's fast tree (terra_amd_set_tree_mode); the reference and the oracle only have mode 0."""
+    tree_mode: terra_amd_set_tree_mode of the product (0 replica traversal of the reference tree, 1 fast tree, 2 automatic);
+    None leaves the library's default (automatic). The reference and the oracle only have the reference traversal."""
     scene = lib.scene_create()
-    if tree_mode:
+    if tree_mode is not None and lib.has("terra_amd_set_tree_mode"):
         f = lib.fn("terra_amd_set_tree_mode", C.c_int, [C.c_void_p, C.c_int])
         assert f(scene, tree_mode) == 0
     if d.environment_lighting:      # the reference has no such switch: its environment term never reaches the image

@@ -1,0 +1,64 @@
+"""bench.py --gpus N from a bare shell: the N ranks are started as a CHILD `python -m torch.distributed.run` before any GPU
+call, rank 0's JSON line is relayed and the child's failure becomes the exit code. No GPU is needed to test that plumbing:
+the child is replaced by small stand-in programs; the real child (two gloo ranks sharing the one GPU) runs in the GPU suite."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def test_launcher_command_is_the_drivers_contract():
+    import bench
+    args = bench.parse_args(["--gpus", "4", "--steps", "2", "--warmup", "1"])
+    cmd = bench.launcher_command(args, ["--gpus", "4", "--steps", "2", "--warmup", "1"], 29123)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29123"
+    i = cmd.index(str(ROOT / "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+
+
+def _run_with_child(monkeypatch, capsys, child_source, tmp_path):
+    import bench
+    prog = tmp_path / "child.py"; prog.write_text(child_source)
+    monkeypatch.setattr(bench, "launcher_command", lambda args, argv, port: [sys.executable, str(prog)] + list(argv))
+    args = bench.parse_args(["--gpus", "2"])
+    rc = bench.self_launch(args, ["--gpus", "2"])
+    return rc, capsys.readouterr()
+
+
+def test_self_launch_relays_the_result_line(monkeypatch, capsys, tmp_path):
+    line = json.dumps({"metric": "Msamples/s", "value": 1.0, "n_gpus": 2})
+    rc, io = _run_with_child(monkeypatch, capsys, f"import sys\nprint('noise from a rank')\nprint({line!r})\nprint('more noise')\n", tmp_path)
+    assert rc == 0 and io.out.strip() == line
+
+
+def test_self_launch_fails_loudly(monkeypatch, capsys, tmp_path):
+    rc, io = _run_with_child(monkeypatch, capsys, "import sys\nsys.stderr.write('rank 1 died\\n')\nsys.exit(3)\n", tmp_path)
+    assert rc == 3 and io.out == "" and "rank 1 died" in io.err and "exited with code 3" in io.err
+    rc, io = _run_with_child(monkeypatch, capsys, "print('no json here')\n", tmp_path)
+    assert rc == 1 and "printed no result line" in io.err
+
+
+def test_bare_invocation_with_gpus_gt_1_never_touches_the_gpu_in_the_parent(tmp_path):
+    """the parent must not import torch / the library before it has spawned the ranks: here (no GPU) the child fails, and the
+    parent reports that failure instead of dying on its own GPU check"""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-backend", "gloo", "--spp", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert r.returncode != 0 and "2-rank child exited" in r.stderr and "needs an MI355X" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_two_gloo_ranks_on_one_gpu_started_by_bench_itself():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dist-backend", "gloo", "--spp", "16", "--check", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["sharded_equals_unsharded"] is True and out["dist_backend"] == "gloo" and out["config"]["parallelism"] == "tiles%2"

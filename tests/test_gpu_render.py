@@ -326,6 +326,43 @@ def test_fast_tree_selects_the_same_hits(H, L, name, integ):
     assert b["stats"]["nodes"] < a["stats"]["nodes"] or name in ("cornell", "phong")
 
 
+# ---------------------------------------------------------------------------
+# automatic traversal (the default): leaf-box cull on LDS-resident scenes, fast tree on the others, replica when the
+# numeric containment check fails -- always the replica's image
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,integ", [("cornell", 0), ("cornell", 1), ("cornell", 2), ("phong", 0), ("phong", 6), ("soup40", 2), ("soup9", 0)])
+def test_leaf_box_cull_is_invisible_and_accounted(H, L, name, integ):
+    from test_oracle_vs_reference import soup_scene
+    if name == "cornell":
+        d = scenes.cornell_box(112, 80, 4, integrator=integ)
+    elif name == "phong":
+        d = scenes.cornell_phong(96, 64, 3, integrator=integ)
+    else:
+        d = soup_scene(H, int(name[4:]), 33, integrator=integ); d.width, d.height, d.spp = 72, 48, 3
+    a = render_dev(L, d, calls=True, passes=2, tree_mode=0)
+    b = render_dev(L, d, calls=True, passes=2, tree_mode=2)
+    assert same(H, a["pixels"], b["pixels"]) and same(H, a["acc"], b["acc"]) and np.array_equal(a["rand_calls"], b["rand_calls"])
+    sa, sb = a["stats"], b["stats"]
+    assert sa["tri_culled"] == 0 and sb["tri_culled"] > 0
+    for k in ("rays", "nodes", "hits", "rand_calls", "attr_fetches"):
+        assert sa[k] == sb[k], k
+    assert sb["tri_tests"] + sb["tri_culled"] == sa["tri_tests"]            # every leaf the reference tests is either tested or culled
+    assert sb["tri_tests"] < sa["tri_tests"]
+
+
+def test_automatic_mode_falls_back_per_call_when_the_camera_is_far(H, L):
+    """the containment argument covers ray origins inside the verified range only: a camera beyond it renders in replica mode"""
+    d = scenes.cornell_box(64, 48, 2)
+    d.camera_position = (0.0, 1.0, -40.0)
+    a = render_dev(L, d, calls=True, tree_mode=0)
+    b = render_dev(L, d, calls=True, tree_mode=2)
+    assert same(H, a["pixels"], b["pixels"]) and b["stats"]["tri_culled"] == 0 and b["stats"]["tri_tests"] == a["stats"]["tri_tests"]
+    hall = scenes.sponza_hall(64, 36, 1); hall.camera_position = (0.0, 4.0, -30.0)
+    a = render_dev(L, hall, tree_mode=0); b = render_dev(L, hall, tree_mode=2)
+    assert same(H, a["pixels"], b["pixels"]) and a["stats"]["nodes"] == b["stats"]["nodes"]       # the reference tree was traversed
+
+
 def test_fast_tree_hall_goldens_and_work(H, L):
     """the fast tree reproduces the REFERENCE's image of the 97k-triangle hall with a fraction of the traversal work"""
     g = G(H, "render_hall")

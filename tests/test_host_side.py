@@ -151,3 +151,41 @@ def test_shard_helpers(L):
     assert L.shard_packed_bytes(1920, 1080, 128, 8) == counts[0] * 128 * 128 * 28
     assert runtime.packed_floats_per_rank(1920, 1080, 128, 8) * 4 == L.shard_packed_bytes(1920, 1080, 128, 8)
     assert L.shard_tile_count(64, 64, 0, 0, 1) < 0
+
+
+# ---------------------------------------------------------------------------
+# automatic traversal policy: the commit-time containment check (host only)
+# ---------------------------------------------------------------------------
+
+def _decision(L, d, mode=None):
+    L.clear_error()
+    scene = scenes.build_scene(L, d, tree_mode=mode)
+    ti = runtime.TraversalInfo()
+    assert L.traversal_info(scene, C.byref(ti)) == 0
+    out = (ti.tree_mode, ti.fast_tree, ti.leaf_cull, ti.max_coordinate, ti.note.decode())
+    L.scene_destroy(scene); L.clear_error()
+    return out
+
+
+def test_automatic_traversal_decision(H, L):
+    from test_oracle_vs_reference import soup_scene
+    # default = automatic; the LDS-resident Cornell box takes the leaf-box cull, the 97k-triangle hall the fast tree
+    mode, fast, cull, cmax, note = _decision(L, scenes.cornell_box(32, 32, 1))
+    assert (mode, fast, cull) == (2, 0, 1) and cmax == 2.0 and "leaf-box cull" in note
+    mode, fast, cull, cmax, note = _decision(L, scenes.sponza_hall(32, 18, 1))
+    assert (mode, fast, cull) == (2, 1, 0) and cmax <= 13.0 and "fast tree" in note
+    # explicit modes are obeyed without a check
+    assert _decision(L, scenes.cornell_box(32, 32, 1), 0)[:3] == (0, 0, 0)
+    assert _decision(L, scenes.cornell_box(32, 32, 1), 1)[:3] == (1, 1, 0)
+    # coordinates beyond the range in which the 1e-4 box margin provably exceeds rounding error: replica traversal, with the reason
+    d = soup_scene(H, 300, 9)
+    for o in d.objects:
+        o.triangles = (o.triangles * np.float32(40.0)).astype(np.float32)
+    mode, fast, cull, cmax, note = _decision(L, d)
+    assert (fast, cull) == (0, 0) and cmax > 13.0 and "exceeds" in note and "replica" in note
+    # non-finite coordinates never pass
+    d = soup_scene(H, 50, 10); d.objects[0].triangles[0, 0, 0] = np.float32("nan")
+    assert _decision(L, d)[1:3] == (0, 0)
+    # fewer than 2 triangles: nothing to cull
+    d = soup_scene(H, 1, 11, n_objects=1)
+    assert _decision(L, d)[1:3] == (0, 0)

@@ -1,7 +1,9 @@
 """Randomised device-vs-oracle run on the GPU (not a unit test): random triangle soups (2..2500 triangles, so all three
 kernel layouts: LDS-resident, global/decoupled, fast tree), random preset mixes incl. Phong / GGX / glass, all seven
-integrators, random sample splits. The device image must equal the oracle's (device-twin math) bit for bit (NaNs: same
-positions), and the fast tree must equal the reference tree.
+integrators, random sample splits. The device image in replica mode (tree mode 0) must equal the oracle's (device-twin math)
+bit for bit (NaNs: same positions), and the fast tree (mode 1) and the automatic mode (2: leaf-box cull / fast tree when the
+numeric containment check passes) must equal the replica mode. FUZZ_SCALE multiplies every coordinate: 1 and 2 stay inside the
+check's range (+-13), 4 puts the camera outside (per-call fallback), 100 everything (commit-time fallback).
     python tools/fuzz_vs_oracle.py [iterations] [seed]"""
 import torch  # first
 import ctypes as C, os, sys
@@ -43,6 +45,7 @@ def bits_equal(a, b):
     return np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
 
 
+decided = {"fast": 0, "cull": 0, "replica": 0}
 faults_fn = lib.fn("terra_amd_debug_faults", C.c_longlong, [C.c_void_p]); faults = 0
 bad = 0
 for it in range(n_iter):
@@ -57,7 +60,7 @@ for it in range(n_iter):
     for _ in range(split):
         orp(C.byref(cam), sc, C.byref(fo.fb), 0, 0, W, H, scenes.FRAME_SEED, None)
     outs = []
-    for tree in (0, 1):
+    for tree in (0, 1, 2):
         lib.clear_error()
         s = scenes.build_scene(lib, d, tree_mode=tree); runtime.check(lib.set_sample_split(s, split))
         fb = runtime.DeviceFramebuffer(W, H)
@@ -65,12 +68,16 @@ for it in range(n_iter):
         torch.cuda.synchronize()
         outs.append((fb.results_host()["acc"].copy(), fb.pixels_host().copy()))
         faults += max(0, faults_fn(s))
+        if tree == 2:
+            ti = runtime.TraversalInfo(); runtime.check(lib.traversal_info(s, C.byref(ti)))
+            decided["fast" if ti.fast_tree else "cull" if ti.leaf_cull else "replica"] += 1
         lib.scene_destroy(s)
     ok0 = bits_equal(outs[0][0], fo.results["acc"]) and bits_equal(outs[0][1], fo.pixels)
     ok1 = bits_equal(outs[1][0], outs[0][0]) and bits_equal(outs[1][1], outs[0][1])
-    if not (ok0 and ok1):
-        bad += 1; print("MISMATCH", dict(it=it, tris=n, W=W, H=H, integ=integ, split=split, spp=spp, bounces=d.bounces, tonemap=d.tonemap, env=d.environment_lighting, vs_oracle=ok0, fast_vs_ref=ok1,
+    ok2 = bits_equal(outs[2][0], outs[0][0]) and bits_equal(outs[2][1], outs[0][1])
+    if not (ok0 and ok1 and ok2):
+        bad += 1; print("MISMATCH", dict(it=it, tris=n, W=W, H=H, integ=integ, split=split, spp=spp, bounces=d.bounces, tonemap=d.tonemap, env=d.environment_lighting, vs_oracle=ok0, fast_vs_ref=ok1, auto_vs_ref=ok2,
                                          kinds=[o.material.kind for o in d.objects]))
     fo.destroy(); orc.scene_destroy(so); orc.scene_destroy(sc)
-print(f"{n_iter} cases, {bad} mismatches, {faults} bounds faults, last error: '{runtime.last_error()}'")
+print(f"{n_iter} cases at scale {SCALE:g}, {bad} mismatches, {faults} bounds faults, automatic mode chose {decided}, last error: '{runtime.last_error()}'")
 sys.exit(1 if bad or faults else 0)

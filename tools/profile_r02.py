@@ -1,0 +1,144 @@
+"""rocprofv3 passes of the bench workloads -> profiles/r02_pmc.json + profiles/r02_rocprof_summary.md (run on the GPU box).
+
+    python3 tools/profile_r02.py [--only KEY_SUBSTRING] [--out gpurun_out/r02_prof]
+
+For every configuration below: one `--kernel-trace --stats` run and four separate `--pmc` runs (SQ group 1, SQ group 2,
+FETCH_SIZE, WRITE_SIZE; counters are never combined with tracing) of `python3 bench.py <args> --no-cpu-baseline
+--no-workloads`. This script itself never touches the GPU: every run is a child process with the program right after `--`.
+The JSON it writes is what bench.py's `roofline` reads (keyed like bench.pmc_key); the markdown is the human summary.
+HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section).
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402  (imports nothing GPU-related at module level)
+
+CONFIGS = [
+    # (workload, tree, integrator, split, extra bench args)
+    ("cornell_1080p_512spp", "auto", "simple", 8, ["--steps", "2", "--warmup", "1"]),
+    ("cornell_1080p_512spp", "reference", "simple", 8, ["--steps", "2", "--warmup", "1"]),
+    ("cornell_1080p_512spp_direct", "auto", "direct", 8, ["--steps", "2", "--warmup", "1"]),
+    ("hall_1080p_256spp", "auto", "simple", 1, ["--steps", "2", "--warmup", "1"]),
+    ("hall_1080p_256spp", "reference", "simple", 1, ["--steps", "1", "--warmup", "0"]),
+    ("spheres_1080p_1024spp", "auto", "simple", 8, ["--steps", "1", "--warmup", "1"]),
+]
+PASSES = {
+    "sq1": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU"],
+    "sq2": ["SQ_THREAD_CYCLES_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_BRANCH", "SQ_WAIT_INST_ANY"],
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+}
+
+
+def run(cmd, log):
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    with open(log, "w") as f:
+        p = subprocess.run(cmd, cwd=str(ROOT), env=env, stdout=subprocess.PIPE, stderr=f, text=True)
+    return p.returncode, p.stdout
+
+
+def counters(directory):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
+    for fcsv in glob.glob(f"{directory}/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fcsv)):
+            k = r["Kernel_Name"]
+            if "terra_" not in k:
+                continue
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Grid_Size", "Workgroup_Size")}
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}, meta
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r02_prof"))
+    a = ap.parse_args()
+    out = Path(a.out); out.mkdir(parents=True, exist_ok=True)
+    jpath = out / "r02_pmc.json"
+    result = json.loads(jpath.read_text()) if jpath.exists() else {}
+    md = []
+    digest = bench.source_digest()
+    for wl, tree, integ, split, extra in CONFIGS:
+        key = bench.pmc_key(wl, tree, integ, split, 0)
+        if a.only and a.only not in key:
+            continue
+        tag = key.replace("|", "_").replace("=", "-")
+        args = ["bench.py", "--workload", wl, "--tree", tree, "--sample-split", str(split), "--no-cpu-baseline", "--no-workloads"] + extra
+        d = out / tag; d.mkdir(exist_ok=True)
+        print("==", key, flush=True)
+        rc, so = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d / "trace"), "--", "python3"] + args, d / "trace.err")
+        line = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if rc != 0 or not line:
+            print("  trace run failed", rc, open(d / "trace.err").read()[-500:]); continue
+        bl = json.loads(line[-1])
+        rec = {"source_digest": digest, "kernel_ms": bl["roofline"]["kernel_ms"], "ms_per_step": bl["ms_per_step"], "value": bl["value"], "counters_per_launch": bl["counters_per_launch"],
+               "traversal": bl["config"]["traversal"]}
+        stats_rows = []
+        for fcsv in glob.glob(f"{d}/trace/**/*_kernel_stats.csv", recursive=True):
+            rows = list(csv.reader(open(fcsv)))
+            stats_rows = [rows[0]] + [r for r in rows[1:] if "terra_" in r[0]]
+        allc = {}; meta_r = {}; per_kernel = {}
+        for pname, ctrs in PASSES.items():
+            rc, so = run(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", str(d / pname), "--", "python3"] + args, d / f"{pname}.err")
+            if rc != 0:
+                print("  pass", pname, "failed", rc, open(d / f"{pname}.err").read()[-300:]); continue
+            c, m = counters(d / pname)
+            for k, v in c.items():
+                per_kernel.setdefault(k, {}).update(v)
+                if "terra_render_kernel" in k:
+                    allc.update(v); meta_r = m[k]; rec["kernel_name"] = k.split("(")[0].replace("void ", "")
+            print("  pass", pname, "ok", flush=True)
+        g = allc.get
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+            if g(k) is not None:
+                rec[k] = g(k)
+        if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+            rec["lane_util"] = round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU")), 4)
+        if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_bank_conflict_frac"] = round(g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"), 4)
+        if g("SQ_WAVE_CYCLES") and g("SQ_BUSY_CYCLES"):
+            rec["waves_per_simd"] = round(4 * g("SQ_WAVE_CYCLES") / (g("SQ_BUSY_CYCLES") / 32 * 1024), 3)
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            rec["fetch_size_kb"] = g("FETCH_SIZE"); rec["write_size_kb"] = g("WRITE_SIZE")
+            rec["hbm_bytes_per_launch"] = int((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024)
+        rec["resources"] = meta_r
+        result[key] = rec
+        jpath.write_text(json.dumps(result, indent=1))
+        md.append(f"## {key}\n")
+        md.append("`rocprofv3 --kernel-trace --stats -- python3 " + " ".join(args) + "` (+ separate `--pmc` passes: " + ", ".join(PASSES) + ")\n")
+        md.append("```\n" + "\n".join(",".join(r) for r in stats_rows) + "\n```")
+        md.append(f"bench.py's own HIP-event timing in the traced run: kernel_ms = {bl['roofline']['kernel_ms']}, ms_per_step = {bl['ms_per_step']}, {bl['value']} Msamples/s; traversal: {bl['config']['traversal']}\n")
+        md.append("render kernel, per launch:\n```")
+        for k in sorted(allc):
+            md.append(f"{k:26s} {allc[k]:.6g}")
+        md.append("```")
+        t = bl["roofline"]["kernel_ms"] * 1e-3
+        if g("SQ_INSTS_VALU"):
+            md.append(f"VALU issue = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x {t * 1e3:.2f} ms) = {g('SQ_INSTS_VALU') * 2 / (1024 * 2.4e9 * t):.3f}" +
+                      (f"; lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = {rec.get('lane_util')}" if rec.get("lane_util") else "") +
+                      (f"; LDS bank-conflict share = {rec.get('lds_bank_conflict_frac')}" if rec.get("lds_bank_conflict_frac") is not None else "") +
+                      (f"; waves per SIMD = {rec.get('waves_per_simd')}" if rec.get("waves_per_simd") else ""))
+        if rec.get("hbm_bytes_per_launch"):
+            md.append(f"L2 fabric-side bytes per launch = (2 x {g('FETCH_SIZE'):.1f} + {g('WRITE_SIZE'):.1f}) KB x 1024 = {rec['hbm_bytes_per_launch'] / 1e6:.1f} MB -> {rec['hbm_bytes_per_launch'] / t / 1e9:.1f} GB/s "
+                      f"({rec['hbm_bytes_per_launch'] / t / 8e12:.4f} of the 8 TB/s HBM peak); algorithmic bytes per launch {bl['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB")
+        md.append(f"resources: {meta_r}\n")
+        for k, v in per_kernel.items():
+            if "terra_render_kernel" not in k and "FETCH_SIZE" in v:
+                md.append(f"(other kernel {k.split('(')[0]}: FETCH_SIZE {v.get('FETCH_SIZE', 0):.1f} KB, WRITE_SIZE {v.get('WRITE_SIZE', 0):.1f} KB per launch)")
+        md.append("")
+        (out / "r02_rocprof_summary.md").write_text("# rocprofv3 summaries, round 2 (tools/profile_r02.py; source digest " + digest + ")\n\n" + "\n".join(md))
+    print("wrote", jpath)
+
+
+if __name__ == "__main__":
+    main()

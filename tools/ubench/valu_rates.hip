@@ -1,0 +1,114 @@
+// Issue-rate microbenchmark for the VALU instruction classes the render kernel is made of (dev tool).
+// Each kernel runs `iters` x 16 independent instructions of one class per wave, WAVES waves per SIMD on every CU;
+// cycles per wave-instruction per SIMD = elapsed * clock / (iters * 16 * waves_per_simd).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <int OP>
+__global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float seed, unsigned long long* cyc ) {
+    unsigned long long t0 = __builtin_readcyclecounter();
+    extern __shared__ float lds_dummy[];
+    if ( seed == -1.f ) out[1] = lds_dummy[threadIdx.x];
+    float a[16]; double d[16]; unsigned long long q[16]; unsigned u[16];
+    for ( int i = 0; i < 16; ++i ) { a[i] = seed + i + threadIdx.x; d[i] = a[i]; q[i] = ( unsigned long long ) ( a[i] * 77.f ) | 1ull; u[i] = ( unsigned ) q[i]; }
+    float b = seed * 0.5f + 1.f; double db = b; unsigned long long qb = 6364136223846793005ull; unsigned ub = 0x9E3779B9u + ( unsigned ) seed;
+    for ( int it = 0; it < iters; ++it ) {
+#define F_ADD(i)  asm volatile ( "v_add_f32 %0, %0, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_MUL(i)  asm volatile ( "v_mul_f32 %0, %0, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_FMA(i)  asm volatile ( "v_fma_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_MIN3(i) asm volatile ( "v_min3_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_RCP(i)  asm volatile ( "v_rcp_f32 %0, %0" : "+v"( a[i] ) );
+#define F_SQRT(i) asm volatile ( "v_sqrt_f32 %0, %0" : "+v"( a[i] ) );
+#define F_RSQ(i)  asm volatile ( "v_rsq_f32 %0, %0" : "+v"( a[i] ) );
+#define D_ADD(i)  asm volatile ( "v_add_f64 %0, %0, %1" : "+v"( d[i] ) : "v"( db ) );
+#define D_MUL(i)  asm volatile ( "v_mul_f64 %0, %0, %1" : "+v"( d[i] ) : "v"( db ) );
+#define D_FMA(i)  asm volatile ( "v_fma_f64 %0, %0, %1, %1" : "+v"( d[i] ) : "v"( db ) );
+#define D_RCP(i)  asm volatile ( "v_rcp_f64 %0, %0" : "+v"( d[i] ) );
+#define D_CVT(i)  asm volatile ( "v_cvt_f64_f32 %0, %1" : "=v"( d[i] ) : "v"( a[i] ) );
+#define D_CVTB(i) asm volatile ( "v_cvt_f32_f64 %0, %1" : "=v"( a[i] ) : "v"( d[i] ) );
+#define I_MULLO(i) asm volatile ( "v_mul_lo_u32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_MULHI(i) asm volatile ( "v_mul_hi_u32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_MAD64(i) asm volatile ( "v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"( q[i] ) : "v"( u[i] ), "v"( ub ) : "vcc" );
+#define I_ADD(i)  asm volatile ( "v_add_u32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_LSHLADD(i) asm volatile ( "v_lshl_add_u32 %0, %0, 3, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_CNDMASK(i) asm volatile ( "v_cndmask_b32 %0, %0, %1, vcc" : "+v"( u[i] ) : "v"( ub ) : "vcc" );
+#define I_CMP(i)  asm volatile ( "v_cmp_gt_f32 vcc, %0, %1" : : "v"( a[i] ), "v"( b ) : "vcc" );
+#define I_MUL24(i) asm volatile ( "v_mul_u32_u24 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_ALIGNBIT(i) asm volatile ( "v_alignbit_b32 %0, %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_LSHR64(i) asm volatile ( "v_lshrrev_b64 %0, 18, %0" : "+v"( q[i] ) );
+#define F_DIVSCALE(i) asm volatile ( "v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"( a[i] ) : "v"( b ) : "vcc" );
+#define F_DIVFIXUP(i) asm volatile ( "v_div_fixup_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_DIVFMAS(i) asm volatile ( "v_div_fmas_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) : "vcc" );
+#define S_SALU(i) asm volatile ( "s_add_u32 s20, s20, 1" : : : "s20" );
+        if ( OP == 0 ) { REP16 ( F_ADD ) }
+        if ( OP == 1 ) { REP16 ( F_MUL ) }
+        if ( OP == 2 ) { REP16 ( F_FMA ) }
+        if ( OP == 3 ) { REP16 ( F_MIN3 ) }
+        if ( OP == 4 ) { REP16 ( F_RCP ) }
+        if ( OP == 5 ) { REP16 ( F_SQRT ) }
+        if ( OP == 6 ) { REP16 ( F_RSQ ) }
+        if ( OP == 7 ) { REP16 ( D_ADD ) }
+        if ( OP == 8 ) { REP16 ( D_MUL ) }
+        if ( OP == 9 ) { REP16 ( D_FMA ) }
+        if ( OP == 10 ) { REP16 ( D_RCP ) }
+        if ( OP == 11 ) { REP16 ( D_CVT ) }
+        if ( OP == 12 ) { REP16 ( D_CVTB ) }
+        if ( OP == 13 ) { REP16 ( I_MULLO ) }
+        if ( OP == 14 ) { REP16 ( I_MULHI ) }
+        if ( OP == 15 ) { REP16 ( I_MAD64 ) }
+        if ( OP == 16 ) { REP16 ( I_ADD ) }
+        if ( OP == 17 ) { REP16 ( I_LSHLADD ) }
+        if ( OP == 18 ) { REP16 ( I_CNDMASK ) }
+        if ( OP == 19 ) { REP16 ( I_CMP ) }
+        if ( OP == 20 ) { REP16 ( I_MUL24 ) }
+        if ( OP == 21 ) { REP16 ( I_ALIGNBIT ) }
+        if ( OP == 22 ) { REP16 ( I_LSHR64 ) }
+        if ( OP == 23 ) { REP16 ( F_DIVSCALE ) }
+        if ( OP == 24 ) { REP16 ( F_DIVFIXUP ) }
+        if ( OP == 25 ) { REP16 ( F_DIVFMAS ) }
+        if ( OP == 26 ) { REP16 ( S_SALU ) }
+    }
+    float s = 0; for ( int i = 0; i < 16; ++i ) s += a[i] + ( float ) d[i] + ( float ) q[i] + ( float ) u[i];
+    if ( s == 12345.678f ) out[0] = s;
+    if ( blockIdx.x == 0 && threadIdx.x == 0 ) cyc[0] = __builtin_readcyclecounter() - t0;
+}
+
+template <int OP> void run ( const char* name, int waves_per_simd, float* out, double clock_ghz, int cus ) {
+    const int iters = 60000;
+    const int rounds = 6;
+    dim3 grid ( cus * waves_per_simd * rounds ), block ( 256 );
+    size_t lds = ( 160 * 1024 ) / waves_per_simd - 512;      // exactly waves_per_simd blocks fit a CU
+    hipEvent_t e0, e1; hipEventCreate ( &e0 ); hipEventCreate ( &e1 );
+    static unsigned long long* dc = nullptr; if ( !dc ) hipMalloc ( &dc, 8 );
+    hipFuncSetAttribute ( ( const void* ) bench<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 );
+    bench<OP><<<grid, block, lds>>> ( out, 10, 1.f, dc );
+    hipDeviceSynchronize();
+    hipEventRecord ( e0 );
+    bench<OP><<<grid, block, lds>>> ( out, iters, 1.f, dc );
+    hipEventRecord ( e1 ); hipEventSynchronize ( e1 );
+    float ms; hipEventElapsedTime ( &ms, e0, e1 );
+    unsigned long long hc = 0; hipMemcpy ( &hc, dc, 8, hipMemcpyDeviceToHost );
+    double cyc = ( double ) hc / ( ( double ) iters * 16 * waves_per_simd );
+    double ginst = ( double ) iters * 16 * waves_per_simd * rounds / ( ms * 1e-3 ) / 1e9;
+    printf ( "%-14s waves/SIMD %d  %.3f ms  %.3f G wave-instr/s per SIMD = %.2f cycles at 2.4 GHz (one block: %.2f counter ticks per instr)\n", name, waves_per_simd, ms, ginst, 2.4 / ginst, cyc );
+}
+
+int main ( int argc, char** argv ) {
+    hipDeviceProp_t p; hipGetDeviceProperties ( &p, 0 );
+    double ghz = p.clockRate * 1e-6;
+    printf ( "%s CUs %d clock %.2f GHz\n", p.name, p.multiProcessorCount, ghz );
+    float* out; hipMalloc ( &out, 4 );
+    for ( int w : { 1, 2, 4 } ) {
+#define R(op, n) run<op> ( n, w, out, ghz, p.multiProcessorCount );
+        R ( 0, "v_add_f32" ) R ( 1, "v_mul_f32" ) R ( 2, "v_fma_f32" ) R ( 3, "v_min3_f32" ) R ( 4, "v_rcp_f32" ) R ( 5, "v_sqrt_f32" ) R ( 6, "v_rsq_f32" )
+        R ( 7, "v_add_f64" ) R ( 8, "v_mul_f64" ) R ( 9, "v_fma_f64" ) R ( 10, "v_rcp_f64" ) R ( 11, "v_cvt_f64_f32" ) R ( 12, "v_cvt_f32_f64" )
+        R ( 13, "v_mul_lo_u32" ) R ( 14, "v_mul_hi_u32" ) R ( 15, "v_mad_u64_u32" ) R ( 16, "v_add_u32" ) R ( 17, "v_lshl_add_u32" ) R ( 18, "v_cndmask" ) R ( 19, "v_cmp_f32" )
+        R ( 20, "v_mul_u32_u24" ) R ( 21, "v_alignbit" ) R ( 22, "v_lshrrev_b64" ) R ( 23, "v_div_scale" ) R ( 24, "v_div_fixup" ) R ( 25, "v_div_fmas" )
+    }
+    return 0;
+}
