@@ -209,6 +209,18 @@ int terra_amd_unit_camera ( const TerraCamera* camera, size_t fb_width, size_t f
 int terra_amd_unit_tonemap ( int op, float gamma, int n, float* colors3 );
 /* device math: fn 0 sinf, 1 cosf, 2 powf(x,y), 3 acosf, 4 atan2f(x,y) */
 int terra_amd_unit_math ( int fn, int n, const float* x, const float* y, float* out );
+/* SURVEY.md 8f N4, unit level. The reference constructs these samplers and never draws from them on the render path
+   (src/Terra.c:535-548) and nothing calls its distributions; they are provided and pinned as stand-alone device functions.
+   terra_sampler_stratified_next_pair (src/Terra.c:714-723) for one sampler per seed: out2[nseeds][n][2]; n <= strata^2 * samples_per_stratum */
+int terra_amd_unit_stratified ( const uint32_t* seeds, int nseeds, int strata, int samples_per_stratum, int n, float* out2 );
+/* terra_sampler_halton_next_pair (src/Terra.c:734-755), elements first .. first+n-1 of the (base 3, base 2) sequence: out2[n][2] */
+int terra_amd_unit_halton ( int first, int n, float* out2 );
+/* terra_distribution_1d_init + _sample (src/Terra.c:760-810): builds the distribution over f[n] on the device and samples it at e[m]:
+   x[m] (FLT_MAX when no bucket holds e: the reference asserts), pdf[m], idx[m]; cdf_out[n] / integral_out optional */
+int terra_amd_unit_distribution_1d ( const float* f, size_t n, const float* e, int m, float* x, float* pdf, uint32_t* idx, float* cdf_out, float* integral_out );
+/* terra_distribution_2d_init + _sample (src/Terra.c:812-846) over f[ny][nx] at (e1,e2)[m]: xy2[m][2] = (row coordinate, column
+   coordinate) as the reference returns them, pdf[m]; marginal_cdf_out[ny] optional */
+int terra_amd_unit_distribution_2d ( const float* f, size_t nx, size_t ny, const float* e12, int m, float* xy2, float* pdf, float* marginal_cdf_out );
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,52 @@ void ref_pcg_floats ( uint32_t seed, int n, float* out ) {
     }
 }
 
+/* ---- SURVEY.md 8f N4, unit level: the reference's stratified / Halton samplers and 1D / 2D distributions
+   (src/Terra.c:703-755, 760-846), driven through their own entry points. Nothing in the reference calls them
+   on the render path (the hemisphere sampler is constructed and ignored, src/Terra.c:535-548). */
+void ref_stratified_pairs ( uint32_t seed, int strata, int samples, int n, float* out2 ) {
+    ref_seed = seed;
+    TerraSamplerRandom r;
+    terra_sampler_random_init ( &r );
+    TerraSamplerStratified s;
+    terra_sampler_stratified_init ( &s, &r, strata, samples );
+    for ( int i = 0; i < n; ++i ) terra_sampler_stratified_next_pair ( &s, out2 + 2 * i, out2 + 2 * i + 1 );
+}
+void ref_halton_pairs ( int first, int n, float* out2 ) {
+    TerraSamplerHalton h;
+    terra_sampler_halton_init ( &h );
+    h.next = first;
+    for ( int i = 0; i < n; ++i ) terra_sampler_halton_next_pair ( &h, out2 + 2 * i, out2 + 2 * i + 1 );
+}
+float ref_radical_inverse ( uint64_t base, uint64_t a ) { return terra_radical_inverse ( base, a ); }
+/* builds the distribution over f[n], returns its cdf / integral, and samples it at e[m] (every e must be below the last cdf
+   entry: the reference asserts otherwise) */
+void ref_distribution_1d ( const float* f, size_t n, const float* e, int m, float* x, float* pdf, uint32_t* idx, float* cdf_out, float* integral_out ) {
+    TerraDistribution1D d;
+    terra_distribution_1d_init ( &d, f, n );
+    if ( cdf_out ) memcpy ( cdf_out, d.cdf, n * sizeof ( float ) );
+    if ( integral_out ) *integral_out = d.integral;
+    for ( int i = 0; i < m; ++i ) {
+        size_t k = 0; float p = 0.f;
+        x[i] = terra_distribution_1d_sample ( &d, e[i], &p, &k );
+        pdf[i] = p; idx[i] = ( uint32_t ) k;
+    }
+    terra_free ( d.cdf ); terra_free ( d.f );
+}
+void ref_distribution_2d ( const float* f, size_t nx, size_t ny, const float* e12, int m, float* xy2, float* pdf, float* marginal_cdf_out ) {
+    TerraDistributon2D d;
+    d.conditionals = ( TerraDistribution1D* ) terra_malloc ( sizeof ( TerraDistribution1D ) * ny );    /* the reference's init expects the rows allocated */
+    terra_distribution_2d_init ( &d, f, nx, ny );
+    if ( marginal_cdf_out ) memcpy ( marginal_cdf_out, d.marginal.cdf, ny * sizeof ( float ) );
+    for ( int i = 0; i < m; ++i ) {
+        float p = 0.f;
+        TerraFloat2 s = terra_distribution_2d_sample ( &d, e12[2 * i], e12[2 * i + 1], &p );
+        xy2[2 * i] = s.x; xy2[2 * i + 1] = s.y; pdf[i] = p;
+    }
+    for ( size_t i = 0; i < ny; ++i ) { terra_free ( d.conditionals[i].cdf ); terra_free ( d.conditionals[i].f ); }
+    terra_free ( d.conditionals ); terra_free ( d.marginal.cdf ); terra_free ( d.marginal.f );
+}
+
 /* ---- per-pixel rendering ---------------------------------------------------
    One terra_render() call per pixel, streams re-keyed before each call, so the
    image does not depend on pixel visit order ("Per-pixel

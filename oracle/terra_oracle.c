@@ -266,6 +266,103 @@ void orc_pcg_floats ( uint32_t seed, int n, float* out ) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* N4, unit level: stratified / Halton samplers, 1D / 2D        */
+/* distributions (reference src/Terra.c:703-755, 760-846). The reference        */
+/* constructs a stratified or Halton sampler per pixel and never draws from it  */
+/* (src/Terra.c:535-548); the distributions have no caller at all. Restated so  */
+/* that the device versions can be pinned to the compiled reference.            */
+/* ------------------------------------------------------------------------- */
+/* terra_sampler_stratified_next_pair (src/Terra.c:714-723): stratum = next / samples, x = stratum % strata, y = stratum / strata;
+   (size_t + float) is a float sum; the clamp is (float)(1.f - 1e-4) with the subtraction in double */
+void orc_stratified_pairs ( uint32_t seed, int strata, int samples, int n, float* out2 ) {
+    OrcPcg32 g; pcgA_init ( &g, seed );
+    const float stratum_size = 1.f / strata;
+    const float top = ( float ) ( 1.f - terra_Epsilon );
+    for ( int next = 0; next < n; ++next ) {
+        size_t stratum = ( size_t ) next / ( size_t ) samples;
+        size_t x = stratum % ( size_t ) strata, y = stratum / ( size_t ) strata;
+        float a = ( ( float ) x + pcgA_nextf ( &g ) ) * stratum_size;
+        float b = ( ( float ) y + pcgA_nextf ( &g ) ) * stratum_size;
+        out2[2 * next] = sel_min ( a, top );
+        out2[2 * next + 1] = sel_min ( b, top );
+    }
+}
+/* terra_radical_inverse (src/Terra.c:734-748): digits reversed in integer arithmetic, denominator as a float product */
+float orc_radical_inverse ( uint64_t base, uint64_t a ) {
+    float inv_base = 1.f / ( float ) base;
+    uint64_t seq = 0;
+    float denom = 1;
+    while ( a ) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        seq = seq * base + digit;
+        denom *= inv_base;
+        a = next;
+    }
+    return sel_min ( ( float ) seq * denom, ( float ) ( 1.f - terra_Epsilon ) );
+}
+/* terra_sampler_halton_next_pair (src/Terra.c:750-755): bases 3 and 2 (src/Terra.c:725-729); `next` is an int */
+void orc_halton_pairs ( int first, int n, float* out2 ) {
+    for ( int i = 0; i < n; ++i ) {
+        out2[2 * i] = orc_radical_inverse ( 3, ( uint64_t ) ( first + i ) );
+        out2[2 * i + 1] = orc_radical_inverse ( 2, ( uint64_t ) ( first + i ) );
+    }
+}
+/* terra_distribution_1d_init (src/Terra.c:760-780): running float sum, then every entry divided by the total */
+static float dist1d_init ( const float* f, size_t n, float* cdf ) {
+    float integral = 0;
+    for ( size_t i = 0; i < n; ++i ) { integral += f[i]; cdf[i] = integral; }
+    for ( size_t i = 0; i < n; ++i ) cdf[i] /= integral;
+    return integral;
+}
+/* terra_distribution_1d_sample (src/Terra.c:781-810): first bucket with e < cdf[i], linear interpolation inside it;
+   (size_t + float) / size_t in float. The reference asserts when no bucket is found; here: FLT_MAX, pdf and idx untouched */
+static float dist1d_sample ( const float* f, const float* cdf, size_t n, float integral, float e, float* pdf, uint32_t* idx ) {
+    float prev = 0;
+    for ( size_t i = 0; i < n; ++i ) {
+        float curr = cdf[i];
+        if ( e < curr ) {
+            if ( pdf ) *pdf = f[i] / integral;
+            if ( idx ) *idx = ( uint32_t ) i;
+            float d = e - prev;
+            d /= curr - prev;
+            return ( ( float ) i + d ) / ( float ) n;
+        }
+        prev = curr;
+    }
+    return FLT_MAX;
+}
+void orc_distribution_1d ( const float* f, size_t n, const float* e, int m, float* x, float* pdf, uint32_t* idx, float* cdf_out, float* integral_out ) {
+    float* cdf = ( float* ) malloc ( sizeof ( float ) * ( n ? n : 1 ) );
+    float integral = dist1d_init ( f, n, cdf );
+    if ( cdf_out ) memcpy ( cdf_out, cdf, n * sizeof ( float ) );
+    if ( integral_out ) *integral_out = integral;
+    for ( int i = 0; i < m; ++i ) { pdf[i] = 0.f; idx[i] = 0; x[i] = dist1d_sample ( f, cdf, n, integral, e[i], &pdf[i], &idx[i] ); }
+    free ( cdf );
+}
+/* terra_distribution_2d_init / _sample (src/Terra.c:812-846): one 1D distribution per row, the marginal over the rows' integrals;
+   sample the row with e1, then the column inside that row with e2; pdf = product */
+void orc_distribution_2d ( const float* f, size_t nx, size_t ny, const float* e12, int m, float* xy2, float* pdf, float* marginal_cdf_out ) {
+    const size_t cells = nx * ny;
+    float* cdf = ( float* ) malloc ( sizeof ( float ) * ( cells > 0 ? cells : 1 ) );
+    float* integrals = ( float* ) malloc ( sizeof ( float ) * ( ny ? ny : 1 ) );
+    float* mcdf = ( float* ) malloc ( sizeof ( float ) * ( ny ? ny : 1 ) );
+    for ( size_t i = 0; i < ny; ++i ) integrals[i] = dist1d_init ( f + nx * i, nx, cdf + nx * i );
+    float integral = 0;
+    for ( size_t i = 0; i < ny; ++i ) { integral += integrals[i]; mcdf[i] = integral; }
+    for ( size_t i = 0; i < ny; ++i ) mcdf[i] /= integral;
+    if ( marginal_cdf_out ) memcpy ( marginal_cdf_out, mcdf, ny * sizeof ( float ) );
+    for ( int k = 0; k < m; ++k ) {
+        float p0 = 0.f, p1 = 0.f; uint32_t row = 0;
+        float s1 = dist1d_sample ( integrals, mcdf, ny, integral, e12[2 * k], &p0, &row );
+        if ( s1 == FLT_MAX ) { xy2[2 * k] = xy2[2 * k + 1] = FLT_MAX; pdf[k] = 0.f; continue; }       /* (the reference would read an uninitialised row index) */
+        float s2 = dist1d_sample ( f + nx * row, cdf + nx * row, nx, integrals[row], e12[2 * k + 1], &p1, NULL );
+        xy2[2 * k] = s1; xy2[2 * k + 1] = s2; pdf[k] = p0 * p1;
+    }
+    free ( cdf ); free ( integrals ); free ( mcdf );
+}
+
+/* ------------------------------------------------------------------------- */
 /* A10/A11: rays and camera (reference src/Terra.c:1702-1724, :1770-1799)      */
 /* ------------------------------------------------------------------------- */
 static OrcRay make_ray ( v3 o, v3 d ) {

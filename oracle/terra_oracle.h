@@ -92,6 +92,12 @@ void     orc_render_pixels_mt ( const TerraCamera* camera, HTerraScene scene, co
 
 /* ---- unit-level entry points (same shapes as oracle/ref_wrapper.c's ref_*) -- */
 void        orc_pcg_floats ( uint32_t seed, int n, float* out );
+/* SURVEY.md 8f N4, unit level (reference src/Terra.c:703-755, 760-846) */
+void        orc_stratified_pairs ( uint32_t seed, int strata, int samples, int n, float* out2 );
+void        orc_halton_pairs ( int first, int n, float* out2 );
+float       orc_radical_inverse ( uint64_t base, uint64_t a );
+void        orc_distribution_1d ( const float* f, size_t n, const float* e, int m, float* x, float* pdf, uint32_t* idx, float* cdf_out, float* integral_out );
+void        orc_distribution_2d ( const float* f, size_t nx, size_t ny, const float* e12, int m, float* xy2, float* pdf, float* marginal_cdf_out );
 int         orc_ray_aabb ( const TerraFloat3* origin, const TerraFloat3* dir, const TerraAABB* box, float* tmin, float* tmax );
 int         orc_watertight ( const TerraFloat3* origin, const TerraFloat3* dir, const TerraTriangle* tri, float* out8 );
 int         orc_moller_trumbore ( const TerraFloat3* origin, const TerraFloat3* dir, const TerraTriangle* tri, float* out4 );

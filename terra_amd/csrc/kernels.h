@@ -25,3 +25,8 @@ hipError_t terra_unit_bsdf ( int kind, int n, float* surfaces47, const float* e3
 hipError_t terra_unit_camera ( const DevRenderParams& p, int n, const uint32_t* xy2, const float* r2, float* dirs3 );
 hipError_t terra_unit_tonemap ( int op, float gamma, int n, float* colors3 );
 hipError_t terra_unit_math ( int fn, int n, const float* x, const float* y, float* out );
+// SURVEY.md 8f N4 (sampling_device.h): cdf / integrals / monotone are device scratch the caller provides (sizes in scene_host.cpp)
+hipError_t terra_unit_stratified ( const uint32_t* seeds, int nseeds, int strata, int samples, int n, float* out2 );
+hipError_t terra_unit_halton ( int first, int n, float* out2 );
+hipError_t terra_unit_distribution_1d ( const float* f, uint32_t n, float* cdf, float* integral, uint32_t* monotone, const float* e, int m, float* x, float* pdf, uint32_t* idx );
+hipError_t terra_unit_distribution_2d ( const float* f, uint32_t nx, uint32_t ny, float* cdf, float* integrals, float* mcdf, uint32_t* monotone, const float* e12, int m, float* xy2, float* pdf );

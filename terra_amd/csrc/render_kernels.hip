@@ -206,6 +206,20 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
     return true;
 }
 
+// a returned path segment's hit: the surface the reference's terra_scene_raycast hands to terra_trace (src/Terra.c:1640-1655)
+template <int COUNT, int MODE, int KINDS>
+TD V3 shade_surface ( const Tracer& T, const Ray& ray, const Closest& best, Surface& sf, Counters& c ) {
+    Ray r = ray; r.o = r.o + r.d * 0.001f;           // the offset scene_raycast applies (src/Terra.c:1629-1630)
+    V3 point = r.o + r.d * best.depth;
+    uint32_t object, tri_in_object, nattr;
+    surface_init<MODE, KINDS> ( T, best.tri, point, sf, object, tri_in_object, nattr );
+    if ( COUNT ) ++c.hits;
+    if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+    return point;
+}
+// a path ended: its radiance joins the pixel's sum of this call (parked in LDS, see TERRA_AUX_WORDS)
+TD void deposit ( float* acc_lds, V3 Lo ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; }
+
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
@@ -262,40 +276,22 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, lt.best.tri, point, lsf, ray.d );
                         job = 0;
                         if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
-                        else { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false; }
+                        else { deposit ( acc_lds, Lo ); have_ray = false; }
                     }
                 } else if ( have_ray ) {                         // a path segment came back
-                    Ray r = ray; r.o = r.o + r.d * 0.001f;
                     if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        V3 point = r.o + r.d * lt.best.depth;
-                        uint32_t object, tri_in_object, nattr;
-                        surface_init<MODE, KINDS> ( T, lt.best.tri, point, sf, object, tri_in_object, nattr );
-                        if ( COUNT ) ++c.hits;
-                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+                        V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
                         V3 wo = neg ( ray.d );
                         Ray ray_a;
                         pend = mis_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
                         b_o = point + sf.normal * 0.0001f;        // surface_ray ( sf, point, bsdf_dir, 1.f ) without the divisions
-                        float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
-                        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
-                        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
-                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
-                        throughput = had ( throughput, f );
-                        throughput = throughput * dot ( sf.normal, wi );
-                        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
-                        float e3 = randf ( rs.b, c, COUNT );
-                        cont = false;
-                        if ( ! ( e3 > pr ) ) {
-                            throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
-                            cont_o = point + sf.normal * 0.0001f; cont_d = wi;
-                            ++bounce;
-                            cont = bounce <= p.bounces;
-                        }
+                        cont = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
+                        cont_o = point + sf.normal * 0.0001f;     // (the divisions of surface_ray are redone when the ray starts)
                         ray = ray_a; job = 1; start = true;
                     } else {
                         if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
-                        acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false;
+                        deposit ( acc_lds, Lo ); have_ray = false;
                     }
                 }
                 if ( !start ) {
@@ -331,39 +327,20 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     Lo = Lo + ( lt.best.tri == pend.expected ? pend.vis : pend.hid );
                     shadow = false;
                     if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
-                    else { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false; }
+                    else { deposit ( acc_lds, Lo ); have_ray = false; }
                 } else if ( have_ray ) {                         // a path segment came back
-                    Ray r = ray; r.o = r.o + r.d * 0.001f;
                     if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        V3 point = r.o + r.d * lt.best.depth;
-                        uint32_t object, tri_in_object, nattr;
-                        surface_init<MODE, KINDS> ( T, lt.best.tri, point, sf, object, tri_in_object, nattr );
-                        if ( COUNT ) ++c.hits;
-                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
+                        V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
                         V3 wo = neg ( ray.d );
                         Ray shadow_ray;
                         pend = direct_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
-                        float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
-                        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
-                        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
-                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
-                        throughput = had ( throughput, f );
-                        throughput = throughput * dot ( sf.normal, wi );
-                        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
-                        float e3 = randf ( rs.b, c, COUNT );
-                        cont = false;
-                        if ( ! ( e3 > pr ) ) {
-                            throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
-                            V3 off = sf.normal * 0.0001f;       // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are redone when the ray starts
-                            cont_o = point + off; cont_d = wi;
-                            ++bounce;
-                            cont = bounce <= p.bounces;
-                        }
+                        cont = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
+                        cont_o = point + sf.normal * 0.0001f;     // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are redone when the ray starts
                         ray = shadow_ray; shadow = true; start = true;
                     } else {
                         if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
-                        acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; have_ray = false;
+                        deposit ( acc_lds, Lo ); have_ray = false;
                     }
                 }
                 if ( !start ) {                                  // the path ended (or none was started yet): the pixel's next sample
@@ -390,35 +367,18 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
             if ( !lt.traversing && !done ) {
                 bool next = false;
                 if ( have_ray ) {
-                    Ray r = ray; r.o = r.o + r.d * 0.001f;           // the offset scene_raycast applies (src/Terra.c:1629-1630)
                     if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        V3 point = r.o + r.d * lt.best.depth;
-                        uint32_t object, tri_in_object, nattr;
-                        surface_init<MODE, KINDS> ( T, lt.best.tri, point, sf, object, tri_in_object, nattr );
-                        if ( COUNT ) ++c.hits;
-                        if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
-                        V3 wo = neg ( ray.d );
+                        V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
+                        V3 wo = neg ( ray.d ), wi;
                         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, point, wo, throughput, bounce, rs.b, c );
-                        float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
-                        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
-                        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
-                        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
-                        throughput = had ( throughput, f );
-                        throughput = throughput * dot ( sf.normal, wi );
-                        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
-                        float e3 = randf ( rs.b, c, COUNT );
-                        if ( ! ( e3 > pr ) ) {
-                            throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
-                            ray = surface_ray ( sf, point, wi, 1.f );
-                            ++bounce;
-                            next = bounce <= p.bounces;
-                        }
+                        next = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
+                        if ( next ) ray = surface_ray ( sf, point, wi, 1.f );
                     } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {
                         throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
                         Lo = Lo + throughput;
                     }
-                    if ( !next ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; }
+                    if ( !next ) deposit ( acc_lds, Lo );
                 }
                 if ( !next ) {
                     if ( s == p.chunk_spp ) { done = true; have_ray = false; }
@@ -448,29 +408,15 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         bool end = !h.hit;
         if ( h.hit ) {
             PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
-            V3 wo = neg ( ray.d );
+            V3 wo = neg ( ray.d ), wi;
             Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
-            float e0 = randf ( rs.b, c, COUNT ), e1 = randf ( rs.b, c, COUNT ), e2 = randf ( rs.b, c, COUNT );
-            V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
-            float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
-            V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
-            throughput = had ( throughput, f );
-            throughput = throughput * dot ( sf.normal, wi );
-            float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
-            float e3 = randf ( rs.b, c, COUNT );
-            if ( e3 > pr ) {
-                end = true;
-            } else {
-                throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
-                ray = surface_ray ( sf, h.point, wi, 1.f );
-                ++bounce;
-                end = bounce > p.bounces;
-            }
+            end = !path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
+            if ( !end ) ray = surface_ray ( sf, h.point, wi, 1.f );
         } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
             throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
             Lo = Lo + throughput;
         }
-        if ( end ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; alive = false; }
+        if ( end ) { deposit ( acc_lds, Lo ); alive = false; }
     }
     }
 

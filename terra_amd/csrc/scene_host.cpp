@@ -1076,3 +1076,36 @@ extern "C" int terra_amd_unit_math ( int fn, int n, const float* x, const float*
     Unit u; auto a = u.in ( x, n ); auto b = u.in ( y ? y : x, n ); auto o = u.out ( out, n );
     return u.finish ( u.ok ? terra_unit_math ( fn, n, a, b, o ) : hipSuccess );
 }
+
+// ---- SURVEY.md 8f N4, unit level (reference src/Terra.c:703-755, 760-846) ------------------------------------------------------
+extern "C" int terra_amd_unit_stratified ( const uint32_t* seeds, int nseeds, int strata, int samples_per_stratum, int n, float* out2 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    if ( nseeds < 0 || n < 0 || strata < 1 || samples_per_stratum < 1 ) return fail ( kTerraAmdErrBadArgument, "stratified sampler: strata and samples per stratum must be positive" );
+    if ( ( long long ) n > ( long long ) strata * strata * samples_per_stratum ) return fail ( kTerraAmdErrBadArgument, "stratified sampler: %d pairs requested but strata^2 * samples = %lld (the reference asserts, src/Terra.c:716)", n, ( long long ) strata * strata * samples_per_stratum );
+    Unit u; auto ds = u.in ( seeds, nseeds ); auto o = u.out ( out2, ( size_t ) nseeds * n * 2 );
+    return u.finish ( u.ok ? terra_unit_stratified ( ds, nseeds, strata, samples_per_stratum, n, o ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_halton ( int first, int n, float* out2 ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    if ( first < 0 || n < 0 ) return fail ( kTerraAmdErrBadArgument, "halton: negative index" );
+    Unit u; auto o = u.out ( out2, ( size_t ) n * 2 );
+    return u.finish ( u.ok ? terra_unit_halton ( first, n, o ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_distribution_1d ( const float* f, size_t n, const float* e, int m, float* x, float* pdf, uint32_t* idx, float* cdf_out, float* integral_out ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    if ( n == 0 || n > 0x7fffffffu || m < 0 ) return fail ( kTerraAmdErrBadArgument, "distribution: empty table" );
+    std::vector<float> cdf_tmp ( cdf_out ? 0 : n ); float integral_tmp = 0.f; uint32_t mono = 0;
+    Unit u; auto df = u.in ( f, n ); auto de = u.in ( e, ( size_t ) m );
+    auto dc = u.out ( cdf_out ? cdf_out : cdf_tmp.data(), n ); auto di = u.out ( integral_out ? integral_out : &integral_tmp, 1 ); auto dm = u.out ( &mono, 1 );
+    auto dx = u.out ( x, ( size_t ) m ); auto dp = u.out ( pdf, ( size_t ) m ); auto dk = u.out ( idx, ( size_t ) m );
+    return u.finish ( u.ok ? terra_unit_distribution_1d ( df, ( uint32_t ) n, dc, di, dm, de, m, dx, dp, dk ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_distribution_2d ( const float* f, size_t nx, size_t ny, const float* e12, int m, float* xy2, float* pdf, float* marginal_cdf_out ) {
+    if ( need_device() ) return kTerraAmdErrNoDevice;
+    if ( nx == 0 || ny == 0 || nx * ny > 0x7fffffffu || m < 0 ) return fail ( kTerraAmdErrBadArgument, "distribution: empty table" );
+    std::vector<float> cdf ( nx * ny ), integrals ( ny + 1 ), mcdf_tmp ( marginal_cdf_out ? 0 : ny ); std::vector<uint32_t> mono ( ny + 1 );
+    Unit u; auto df = u.in ( f, nx * ny ); auto de = u.in ( e12, ( size_t ) m * 2 );
+    auto dc = u.out ( cdf.data(), nx * ny ); auto di = u.out ( integrals.data(), ny + 1 ); auto dmc = u.out ( marginal_cdf_out ? marginal_cdf_out : mcdf_tmp.data(), ny ); auto dm = u.out ( mono.data(), ny + 1 );
+    auto dxy = u.out ( xy2, ( size_t ) m * 2 ); auto dp = u.out ( pdf, ( size_t ) m );
+    return u.finish ( u.ok ? terra_unit_distribution_2d ( df, ( uint32_t ) nx, ( uint32_t ) ny, dc, di, dmc, dm, de, m, dxy, dp ) : hipSuccess );
+}

@@ -319,53 +319,62 @@ struct Closest { float depth; uint32_t tri; };
 #define TERRA_PUSH(T, top, v) do { if ( TERRA_CHECK_BOUNDS && ( top ) >= ( T ).stack_cap ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { ( T ).stack[ ( top ) * ( T ).stride] = ( int ) ( v ); ++( top ); } } while ( 0 )
 #define TERRA_LEAF(T, n, v) do { if ( TERRA_CHECK_BOUNDS && ( n ) >= ( T ).leaf_cap ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { ( T ).leaves[ ( n ) * ( T ).stride] = ( int ) ( v ); ++( n ); } } while ( 0 )
 
+// one node of the reference traversal (src/TerraBVH.c:262-303): pop, slab-test both child boxes, push the inner children
+// that are hit, append the leaf children to the lane's list (all of them; with Tracer::cull only those whose box is hit)
 template <int COUNT, int MODE, bool FAST>
-TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
+TD void node_step ( const Tracer& T, const Ray& r, int& top, int& nleaf, Counters& c ) {
     const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
+    PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
+    uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+    float4 q0, q1, q2, q3;
+    if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
+    else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
+    uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+    if ( COUNT ) ++c.nodes;
+    bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
+    bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
+    bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
+    if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
+    if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
+    const bool met0 = leaf0 && child0 != DEV_CHILD_EMPTY, met1 = leaf1 && child1 != DEV_CHILD_EMPTY;
+    if ( met0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
+    if ( met1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
+    if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( met0 && !hit0 ) + ( uint32_t ) ( met1 && !hit1 );
+}
+
+// triangle test of entry i of the lane's leaf list, in the order the leaves were met: strict "<" keeps the first of equal depths
+template <int COUNT, int MODE>
+TD void leaf_step ( const Tracer& T, int i, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
     const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
     const int kx = st.ix, ky = st.iy, kz = st.iz;
+    PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
+    uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
+    float pa[3], pb[3], pc[3];
+    if ( MODE == 1 ) {
+        const float* t = T.l_tris + 12 * ti;
+        pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
+        pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
+        pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
+    } else {
+        float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
+        V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+        pa[0] = pick ( va, kx ); pa[1] = pick ( va, ky ); pa[2] = pick ( va, kz );
+        pb[0] = pick ( vb, kx ); pb[1] = pick ( vb, ky ); pb[2] = pick ( vb, kz );
+        pc[0] = pick ( vc, kx ); pc[1] = pick ( vc, ky ); pc[2] = pick ( vc, kz );
+    }
+    if ( COUNT ) ++c.tri_tests;
+    float depth;
+    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
+}
+
+template <int COUNT, int MODE, bool FAST>
+TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
     int top = 1, nleaf = 0;
     T.stack[0] = 0;
     for ( ;; ) {
         PS_WAVE ( c, kPsDrainIter );
-        while ( top > 0 && nleaf <= T.leaf_cap - 2 ) {
-            PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
-            uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
-            float4 q0, q1, q2, q3;
-            if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
-            else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
-            uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
-            if ( COUNT ) ++c.nodes;
-            bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
-            bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
-            bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
-            if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
-            if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
-            const bool met0 = leaf0 && child0 != DEV_CHILD_EMPTY, met1 = leaf1 && child1 != DEV_CHILD_EMPTY;
-            if ( met0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
-            if ( met1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
-            if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( met0 && !hit0 ) + ( uint32_t ) ( met1 && !hit1 );
-        }
-        for ( int i = 0; i < nleaf; ++i ) {
-            PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
-            uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
-            float pa[3], pb[3], pc[3];
-            if ( MODE == 1 ) {
-                const float* t = T.l_tris + 12 * ti;
-                pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
-                pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
-                pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
-            } else {
-                float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
-                V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
-                pa[0] = pick ( va, kx ); pa[1] = pick ( va, ky ); pa[2] = pick ( va, kz );
-                pb[0] = pick ( vb, kx ); pb[1] = pick ( vb, ky ); pb[2] = pick ( vb, kz );
-                pc[0] = pick ( vc, kx ); pc[1] = pick ( vc, ky ); pc[2] = pick ( vc, kz );
-            }
-            if ( COUNT ) ++c.tri_tests;
-            float depth;
-            if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
-        }
+        while ( top > 0 && nleaf <= T.leaf_cap - 2 ) node_step<COUNT, MODE, FAST> ( T, r, top, nleaf, c );
+        for ( int i = 0; i < nleaf; ++i ) leaf_step<COUNT, MODE> ( T, i, st, o_perm, best, c );
         nleaf = 0;
         if ( top <= 0 ) break;
     }
@@ -466,51 +475,14 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
 // -----------------------------------------------------------------------------
 template <int COUNT, int MODE, bool FAST>
 TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, int& top, int& nleaf, bool& traversing, int exit_active, Counters& c ) {
-    const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
-    const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
-    const int kx = st.ix, ky = st.iy, kz = st.iz;
     for ( ;; ) {
         for ( ;; ) {
             const bool can = traversing && top > 0 && nleaf <= T.leaf_cap - 2;
             const int n_can = __popcll ( __ballot ( can ) ), n_nodes = __popcll ( __ballot ( traversing && top > 0 ) );
             if ( n_can == 0 || n_nodes <= exit_active ) break;
-            if ( can ) {
-                uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
-                float4 q0, q1, q2, q3;
-                if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
-                else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
-                uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
-                if ( COUNT ) ++c.nodes;
-                bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
-                bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
-                bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
-                if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
-                if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
-                const bool met0 = leaf0 && child0 != DEV_CHILD_EMPTY, met1 = leaf1 && child1 != DEV_CHILD_EMPTY;
-                if ( met0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
-                if ( met1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
-                if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( met0 && !hit0 ) + ( uint32_t ) ( met1 && !hit1 );
-            }
+            if ( can ) node_step<COUNT, MODE, FAST> ( T, r, top, nleaf, c );
         }
-        for ( int i = 0; i < nleaf; ++i ) {         // lanes that are not traversing hold nleaf == 0
-            uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
-            float pa[3], pb[3], pc[3];
-            if ( MODE == 1 ) {
-                const float* t = T.l_tris + 12 * ti;
-                pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
-                pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
-                pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
-            } else {
-                float4 a = g_tris[3 * ti], b = g_tris[3 * ti + 1], cc = g_tris[3 * ti + 2];
-                V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
-                pa[0] = pick ( va, kx ); pa[1] = pick ( va, ky ); pa[2] = pick ( va, kz );
-                pb[0] = pick ( vb, kx ); pb[1] = pick ( vb, ky ); pb[2] = pick ( vb, kz );
-                pc[0] = pick ( vc, kx ); pc[1] = pick ( vc, ky ); pc[2] = pick ( vc, kz );
-            }
-            if ( COUNT ) ++c.tri_tests;
-            float depth;
-            if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
-        }
+        for ( int i = 0; i < nleaf; ++i ) leaf_step<COUNT, MODE> ( T, i, st, o_perm, best, c );         // lanes that are not traversing hold nleaf == 0
         nleaf = 0;
         if ( traversing && top <= 0 ) traversing = false;
         if ( __popcll ( __ballot ( traversing ) ) <= exit_active ) break;
@@ -1069,6 +1041,25 @@ TD V3 integrate ( const Tracer& T, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 
     }
 }
 
+// The tail of one terra_trace iteration after the integrator's term (reference src/Terra.c:1066-1094): sample the BSDF, weight the
+// throughput, play Russian roulette. Returns true when the path goes on (then `bounce` was advanced and wi is the next direction; the
+// caller forms the next ray from the hit point). Same operations, draws and order in all four loops of the kernel.
+template <int COUNT, int KINDS>
+TD bool path_continue ( Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, uint32_t max_bounces, Pcg32& rb, Counters& c, V3& wi ) {
+    float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
+    wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+    float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
+    V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
+    throughput = had ( throughput, f );
+    throughput = throughput * dot ( sf.normal, wi );
+    float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
+    float e3 = randf ( rb, c, COUNT );
+    if ( e3 > pr ) return false;
+    throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+    ++bounce;
+    return bounce <= max_bounces;
+}
+
 // -----------------------------------------------------------------------------
 // one full path (the reference's terra_trace), used by the unit entry point and,
 // restructured with path regeneration, by the render kernel
@@ -1085,16 +1076,9 @@ TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counte
         }
         V3 wo = neg ( ray.d );
         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rb, c );
-        float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
-        V3 wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
-        float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
-        V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
-        throughput = had ( throughput, f );
-        throughput = throughput * dot ( sf.normal, wi );
-        float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
-        float e3 = randf ( rb, c, COUNT );
-        if ( e3 > pr ) break;
-        throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
+        V3 wi;
+        uint32_t next_bounce = bounce;
+        if ( !path_continue<COUNT, KINDS> ( sf, wo, throughput, next_bounce, bounces, rb, c, wi ) ) break;
         ray = surface_ray ( sf, h.point, wi, 1.f );
     }
     return Lo;

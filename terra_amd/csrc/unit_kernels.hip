@@ -3,6 +3,7 @@
 // oracle and the golden vectors (include/terra_amd.h, "unit-level device entry points").
 #include <hip/hip_runtime.h>
 #include "trace_device.h"
+#include "sampling_device.h"
 #include "kernels.h"
 
 #define UNIT_GRID(n) dim3 ( ( ( n ) + 255 ) / 256 ), dim3 ( 256 )
@@ -218,5 +219,70 @@ __global__ void k_math ( int fn, int n, const float* x, const float* y, float* o
 }
 hipError_t terra_unit_math ( int fn, int n, const float* x, const float* y, float* out ) {
     hipLaunchKernelGGL ( k_math, UNIT_GRID ( n ), 0, 0, fn, n, x, y, out );
+    return hipGetLastError();
+}
+
+
+// ---- SURVEY.md 8f N4, unit level: samplers and distributions (sampling_device.h) ---------------------------------------------
+// one sampler per seed; a stratified sampler's n pairs are inherently sequential (they share one random stream)
+__global__ void k_stratified ( const uint32_t* seeds, int nseeds, int strata, int samples, int n, float* out2 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= nseeds ) return;
+    StratifiedSampler s; stratified_init ( s, seeds[i], strata, samples );
+    for ( int j = 0; j < n; ++j ) { float a, b; stratified_next_pair ( s, a, b ); out2[ ( ( size_t ) i * n + j ) * 2] = a; out2[ ( ( size_t ) i * n + j ) * 2 + 1] = b; }
+}
+hipError_t terra_unit_stratified ( const uint32_t* seeds, int nseeds, int strata, int samples, int n, float* out2 ) {
+    hipLaunchKernelGGL ( k_stratified, UNIT_GRID ( nseeds ), 0, 0, seeds, nseeds, strata, samples, n, out2 );
+    return hipGetLastError();
+}
+__global__ void k_halton ( int first, int n, float* out2 ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    float a, b; halton_pair ( first + i, a, b );
+    out2[2 * i] = a; out2[2 * i + 1] = b;
+}
+hipError_t terra_unit_halton ( int first, int n, float* out2 ) {
+    hipLaunchKernelGGL ( k_halton, UNIT_GRID ( n ), 0, 0, first, n, out2 );
+    return hipGetLastError();
+}
+// rows of a 2D table (ny = 1: a 1D distribution): one lane per row, each a sequential float sum
+__global__ void k_dist_rows ( const float* f, uint32_t nx, uint32_t ny, float* cdf, float* integrals, uint32_t* monotone ) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( r >= ny ) return;
+    integrals[r] = distribution_row_init ( f + ( size_t ) nx * r, nx, cdf + ( size_t ) nx * r, monotone + r );
+}
+// the marginal over the rows' totals (reference src/Terra.c:817-833): one lane, sequential; slot ny of `integrals` / `monotone` receives its total / flag
+__global__ void k_dist_marginal ( uint32_t ny, float* integrals, float* mcdf, uint32_t* monotone ) {
+    if ( blockIdx.x || threadIdx.x ) return;
+    integrals[ny] = distribution_row_init ( integrals, ny, mcdf, monotone + ny );
+}
+__global__ void k_dist_sample_1d ( const float* f, const float* cdf, uint32_t n, const float* integral, const uint32_t* monotone, const float* e, int m, float* x, float* pdf, uint32_t* idx ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= m ) return;
+    DevDistribution1D d = { f, cdf, n, integral[0], monotone[0] };
+    float p = 0.f; uint32_t k = 0;
+    x[i] = distribution_sample ( d, e[i], &p, &k );
+    pdf[i] = p; idx[i] = k;
+}
+__global__ void k_dist_sample_2d ( const float* f, const float* cdf, uint32_t nx, uint32_t ny, const float* integrals, const float* mcdf, const uint32_t* monotone, const float* e12, int m, float* xy2, float* pdf ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= m ) return;
+    DevDistribution1D marginal = { integrals, mcdf, ny, integrals[ny], monotone[ny] };
+    float p0 = 0.f, p1 = 0.f; uint32_t row = 0;
+    const float s1 = distribution_sample ( marginal, e12[2 * i], &p0, &row );
+    if ( s1 == FLT_MAX ) { xy2[2 * i] = xy2[2 * i + 1] = FLT_MAX; pdf[i] = 0.f; return; }
+    DevDistribution1D cond = { f + ( size_t ) nx * row, cdf + ( size_t ) nx * row, nx, integrals[row], monotone[row] };
+    const float s2 = distribution_sample ( cond, e12[2 * i + 1], &p1, nullptr );
+    xy2[2 * i] = s1; xy2[2 * i + 1] = s2; pdf[i] = p0 * p1;
+}
+hipError_t terra_unit_distribution_1d ( const float* f, uint32_t n, float* cdf, float* integral, uint32_t* monotone, const float* e, int m, float* x, float* pdf, uint32_t* idx ) {
+    hipLaunchKernelGGL ( k_dist_rows, dim3 ( 1 ), dim3 ( 64 ), 0, 0, f, n, 1u, cdf, integral, monotone );
+    if ( m > 0 ) hipLaunchKernelGGL ( k_dist_sample_1d, UNIT_GRID ( m ), 0, 0, f, cdf, n, integral, monotone, e, m, x, pdf, idx );
+    return hipGetLastError();
+}
+hipError_t terra_unit_distribution_2d ( const float* f, uint32_t nx, uint32_t ny, float* cdf, float* integrals, float* mcdf, uint32_t* monotone, const float* e12, int m, float* xy2, float* pdf ) {
+    hipLaunchKernelGGL ( k_dist_rows, UNIT_GRID ( ny ), 0, 0, f, nx, ny, cdf, integrals, monotone );
+    hipLaunchKernelGGL ( k_dist_marginal, dim3 ( 1 ), dim3 ( 64 ), 0, 0, ny, integrals, mcdf, monotone );
+    if ( m > 0 ) hipLaunchKernelGGL ( k_dist_sample_2d, UNIT_GRID ( m ), 0, 0, f, cdf, nx, ny, integrals, mcdf, monotone, e12, m, xy2, pdf );
     return hipGetLastError();
 }

@@ -137,6 +137,28 @@ def main():
         tex[f"i{integ}_pixels"] = o6["pixels"]; tex[f"i{integ}_calls"] = o6["rand_calls"].astype(np.uint16)
     manifest["files"]["render_textured"] = save("render_textured", **tex)
 
+    # SURVEY 8f N4 (unit level): stratified / Halton samplers, 1D / 2D distributions (reference src/Terra.c:703-846)
+    smp = {}
+    seeds = np.array([0, 7, 0x5EED0001, 0xFFFFFFFF], np.uint32)
+    for strata, samples in ((1, 1), (2, 3), (4, 16), (7, 2)):
+        smp[f"strat_{strata}_{samples}"] = ref.stratified(seeds, strata, samples, strata * strata * samples)
+    smp["seeds"] = seeds
+    smp["halton_0"] = ref.halton(0, 4096)
+    smp["halton_far"] = ref.halton(2 ** 30, 512)
+    tables, e, t2, e12 = H.sampler_cases()
+    smp["e"] = e; smp["e12"] = e12
+    for name, f in tables.items():
+        o7 = ref.distribution_1d(f, e)
+        smp[f"d1_{name}_f"] = f
+        for k, v in o7.items():
+            smp[f"d1_{name}_{k}"] = v
+    for name, f in t2.items():
+        o8 = ref.distribution_2d(f, e12)
+        smp[f"d2_{name}_f"] = f
+        for k, v in o8.items():
+            smp[f"d2_{name}_{k}"] = v
+    manifest["files"]["samplers"] = save("samplers", **smp)
+
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1))
     total = sum(p.stat().st_size for p in HERE.glob("*.npz"))
     print(f"wrote {len(manifest['files'])} fixtures, {total / 1e6:.2f} MB")

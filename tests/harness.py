@@ -199,6 +199,46 @@ class Unit:
                     surf[i] = np.frombuffer(bytes(s), dtype=np.float32)
         return obj, tri, point, surf
 
+    # -- samplers and distributions (unit level)
+    def stratified(self, seeds, strata, samples, n):
+        seeds = np.asarray(seeds, np.uint32)
+        out = np.zeros((len(seeds), n, 2), np.float32)
+        if self.kind == "amd":
+            rc = self._f("stratified", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])(seeds.ctypes.data, len(seeds), strata, samples, n, out.ctypes.data)
+            assert rc == 0, last_error()
+        else:
+            f = self._f("stratified_pairs", None, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p])
+            for i, sd in enumerate(seeds):
+                f(int(sd), strata, samples, n, out[i].ctypes.data)
+        return out
+
+    def halton(self, first, n):
+        out = np.zeros((n, 2), np.float32)
+        if self.kind == "amd":
+            rc = self._f("halton", C.c_int, [C.c_int, C.c_int, C.c_void_p])(first, n, out.ctypes.data)
+            assert rc == 0, last_error()
+        else:
+            self._f("halton_pairs", None, [C.c_int, C.c_int, C.c_void_p])(first, n, out.ctypes.data)
+        return out
+
+    def distribution_1d(self, f, e):
+        f = np.ascontiguousarray(f, np.float32); e = np.ascontiguousarray(e, np.float32); n, m = len(f), len(e)
+        x = np.zeros(m, np.float32); pdf = np.zeros(m, np.float32); idx = np.zeros(m, np.uint32); cdf = np.zeros(n, np.float32); integral = np.zeros(1, np.float32)
+        sig = [C.c_void_p, c_sz, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        res = self._f("distribution_1d", C.c_int if self.kind == "amd" else None, sig)(f.ctypes.data, n, e.ctypes.data, m, x.ctypes.data, pdf.ctypes.data, idx.ctypes.data, cdf.ctypes.data, integral.ctypes.data)
+        if self.kind == "amd":
+            assert res == 0, last_error()
+        return dict(x=x, pdf=pdf, idx=idx, cdf=cdf, integral=integral)
+
+    def distribution_2d(self, f, e12):
+        f = np.ascontiguousarray(f, np.float32); e12 = np.ascontiguousarray(e12, np.float32); ny, nx = f.shape; m = len(e12)
+        xy = np.zeros((m, 2), np.float32); pdf = np.zeros(m, np.float32); mcdf = np.zeros(ny, np.float32)
+        sig = [C.c_void_p, c_sz, c_sz, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        res = self._f("distribution_2d", C.c_int if self.kind == "amd" else None, sig)(f.ctypes.data, nx, ny, e12.ctypes.data, m, xy.ctypes.data, pdf.ctypes.data, mcdf.ctypes.data)
+        if self.kind == "amd":
+            assert res == 0, last_error()
+        return dict(xy=xy, pdf=pdf, marginal_cdf=mcdf)
+
     def trace(self, scene, o, d, stateB, incB):
         n = len(o)
         rad = np.zeros((n, 3), np.float32); calls = np.zeros(n, np.uint32)
@@ -472,3 +512,16 @@ def _basis(n):
         t = np.array([f(f(0) * k), f(f(-nz) * k), f(ny * k)], np.float32)
     b = np.array([f(f(ny * t[2]) - f(nz * t[1])), f(f(nz * t[0]) - f(nx * t[2])), f(f(nx * t[1]) - f(ny * t[0]))], np.float32)
     return np.array([t[0], nx, b[0], 0, t[1], ny, b[1], 0, t[2], nz, b[2], 0, 0, 0, 0, 1], np.float32)
+
+
+def sampler_cases():
+    """inputs of the N4 fixtures (tests/golden/samplers.npz): table sizes from 1 to 1000, tables with zero buckets, variates on the
+    u24 grid incl. 0 and the largest value below 1"""
+    r = rng(91)
+    u24 = lambda n: (r.randint(0, 2 ** 24, size=n).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+    tables = {"n1": np.array([2.5], np.float32), "n7": r.uniform(0.1, 3, 7).astype(np.float32), "n64": r.uniform(0, 1, 64).astype(np.float32),
+              "n1000": (r.uniform(0, 1, 1000) ** 4).astype(np.float32), "zeros": np.array([0, 0, 1, 0, 2, 0, 0, 3, 0], np.float32)}
+    e = u24(400); e[:3] = [0.0, np.float32(1) - np.float32(2.0 ** -24), 0.5]
+    t2 = {"t16x8": r.uniform(0, 1, (8, 16)).astype(np.float32), "t64x32": (r.uniform(0, 1, (32, 64)) ** 3).astype(np.float32), "t5x3": np.array([[0, 1, 0, 2, 0], [3, 0, 0, 0, 1], [0.5, 0.5, 0.5, 0.5, 0.5]], np.float32)}
+    e12 = np.stack([u24(300), u24(300)], axis=1); e12[:2] = [[0.0, 0.0], [np.float32(1) - np.float32(2.0 ** -24)] * 2]
+    return tables, e, t2, np.ascontiguousarray(e12, np.float32)
