@@ -24,6 +24,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-x", "hip", f"--offload-arch={ARCH}", "-std=c++17", "-O3", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    # no SLP vectorisation: on gfx950 a v_pk_mul/add_f32 issues at 0.57 G/s per SIMD against 0.96 for v_mul/v_add_f32 (profiles/r02_measurements/valu_rates.log),
+    # so a packed pair barely beats two scalar instructions and the v_mov shuffles that build the pairs are pure loss: headline 82.6 -> 75.7 ms
+    "-fno-slp-vectorize",
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
 ]
 

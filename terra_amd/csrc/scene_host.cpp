@@ -20,6 +20,7 @@
 #include <string>
 #include <unordered_set>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "../../include/terra_amd.h"
@@ -252,6 +253,11 @@ struct Scene {
 };
 
 static Scene* S ( HTerraScene h ) { return ( Scene* ) h; }
+
+// TERRA_AMD_TIMING=1: commit phases on stderr (tools/scale_triangles.py reads them)
+static bool timing_on() { static const bool on = getenv ( "TERRA_AMD_TIMING" ) != nullptr; return on; }
+static double now_s() { return std::chrono::duration<double> ( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+static void phase ( const char* what, double& t0 ) { if ( !timing_on() ) return; double t = now_s(); fprintf ( stderr, "[terra_amd timing] %-28s %8.2f ms\n", what, ( t - t0 ) * 1e3 ); t0 = t; }
 
 extern "C" HTerraScene terra_scene_create ( void ) {
     Scene* s = new Scene();
@@ -576,7 +582,9 @@ static int upload_scene ( Scene* s ) {
             q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
             q.soup = ( uint32_t ) ( s->first_tri[j] + i );
         }
+        double t_phase = now_s();
         fastbvh::Built built = fastbvh::build ( prims );        // (reorders prims into leaf order)
+        phase ( "fast tree (host)", t_phase );
         std::string why;
         if ( s->tree_mode == 2 && !verify_fast_tree ( built.nodes, prims, why ) ) {       // cannot happen with this builder (plain unions); checked because the culling relies on it
             s->use_fast = false; s->tree_note = why + ": reference tree";
@@ -647,7 +655,8 @@ extern "C" void terra_scene_commit ( HTerraScene h ) {
     const bool rebuild = s->dirty_objects || s->opts.accelerator != s->new_opts.accelerator || s->nodes.empty();
     const bool env_changed = s->env_lighting && memcmp ( &s->opts.environment_map, &s->new_opts.environment_map, sizeof ( TerraAttribute ) ) != 0;
     s->opts = s->new_opts;
-    if ( rebuild ) bvh::build ( s->objects, s->objects_pop, s->nodes, s->max_stack );
+    double t_phase = now_s();
+    if ( rebuild ) { bvh::build ( s->objects, s->objects_pop, s->nodes, s->max_stack ); phase ( "reference tree (host)", t_phase ); }
     const bool relight = s->dirty_lights || rebuild;
     if ( relight ) {
         s->lights.clear();

@@ -44,6 +44,29 @@ __global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float s
 #define F_DIVSCALE(i) asm volatile ( "v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"( a[i] ) : "v"( b ) : "vcc" );
 #define F_DIVFIXUP(i) asm volatile ( "v_div_fixup_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) );
 #define F_DIVFMAS(i) asm volatile ( "v_div_fmas_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) : "vcc" );
+#define P_MUL(i) asm volatile ( "v_pk_mul_f32 %0, %0, %1" : "+v"( d[i] ) : "v"( db ) );
+#define P_ADD(i) asm volatile ( "v_pk_add_f32 %0, %0, %1" : "+v"( d[i] ) : "v"( db ) );
+#define P_FMA(i) asm volatile ( "v_pk_fma_f32 %0, %0, %1, %1" : "+v"( d[i] ) : "v"( db ) );
+#define V_MOV(i) asm volatile ( "v_mov_b32 %0, %1" : "=v"( u[i] ) : "v"( ub ) );
+#define P_MOV(i) asm volatile ( "v_pk_mov_b32 %0, %0, %1" : "+v"( d[i] ) : "v"( db ) );
+#define F_SUB(i) asm volatile ( "v_sub_f32 %0, %0, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_MAX(i) asm volatile ( "v_max_f32 %0, %0, %1" : "+v"( a[i] ) : "v"( b ) );
+#define C_VCC(i) asm volatile ( "v_cndmask_b32 %0, %0, %1, vcc" : "+v"( u[i] ) : "v"( ub ) );
+#define C_SGPR(i) asm volatile ( "v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"( u[i] ) : "v"( ub ) );
+#define F_MIN(i) asm volatile ( "v_min_f32 %0, %0, %1" : "+v"( a[i] ) : "v"( b ) );
+#define I_AND(i) asm volatile ( "v_and_b32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_XOR(i) asm volatile ( "v_xor_b32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_LSHL(i) asm volatile ( "v_lshlrev_b32 %0, 3, %0" : "+v"( u[i] ) );
+#define I_LSHR(i) asm volatile ( "v_lshrrev_b32 %0, 3, %0" : "+v"( u[i] ) );
+#define I_ADD3(i) asm volatile ( "v_add3_u32 %0, %0, %1, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_SUB(i) asm volatile ( "v_sub_u32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define F_MED3(i) asm volatile ( "v_med3_f32 %0, %0, %1, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_CVTU(i) asm volatile ( "v_cvt_f32_u32 %0, %1" : "=v"( a[i] ) : "v"( u[i] ) );
+#define F_FMAC(i) asm volatile ( "v_fmac_f32 %0, %1, %1" : "+v"( a[i] ) : "v"( b ) );
+#define F_MULK(i) asm volatile ( "v_mul_f32 %0, 0x3a83126f, %0" : "+v"( a[i] ) );
+#define I_CMPS(i) asm volatile ( "v_cmp_gt_f32_e64 s[22:23], %0, %1" : : "v"( a[i] ), "v"( b ) : "s22", "s23" );
+#define I_BFE(i) asm volatile ( "v_bfe_u32 %0, %0, 3, 5" : "+v"( u[i] ) );
+#define I_ADDC(i) asm volatile ( "v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"( u[i] ) : "v"( ub ) : "vcc" );
 #define S_SALU(i) asm volatile ( "s_add_u32 s20, s20, 1" : : : "s20" );
         if ( OP == 0 ) { REP16 ( F_ADD ) }
         if ( OP == 1 ) { REP16 ( F_MUL ) }
@@ -72,6 +95,29 @@ __global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float s
         if ( OP == 24 ) { REP16 ( F_DIVFIXUP ) }
         if ( OP == 25 ) { REP16 ( F_DIVFMAS ) }
         if ( OP == 26 ) { REP16 ( S_SALU ) }
+        if ( OP == 27 ) { REP16 ( P_MUL ) }
+        if ( OP == 28 ) { REP16 ( P_ADD ) }
+        if ( OP == 29 ) { REP16 ( P_FMA ) }
+        if ( OP == 30 ) { REP16 ( V_MOV ) }
+        if ( OP == 31 ) { REP16 ( P_MOV ) }
+        if ( OP == 32 ) { REP16 ( F_SUB ) }
+        if ( OP == 33 ) { REP16 ( F_MAX ) }
+        if ( OP == 34 ) { REP16 ( C_VCC ) }
+        if ( OP == 35 ) { REP16 ( C_SGPR ) }
+        if ( OP == 36 ) { REP16 ( F_MIN ) }
+        if ( OP == 37 ) { REP16 ( I_AND ) }
+        if ( OP == 38 ) { REP16 ( I_XOR ) }
+        if ( OP == 39 ) { REP16 ( I_LSHL ) }
+        if ( OP == 40 ) { REP16 ( I_LSHR ) }
+        if ( OP == 41 ) { REP16 ( I_ADD3 ) }
+        if ( OP == 42 ) { REP16 ( I_SUB ) }
+        if ( OP == 43 ) { REP16 ( F_MED3 ) }
+        if ( OP == 44 ) { REP16 ( F_CVTU ) }
+        if ( OP == 45 ) { REP16 ( F_FMAC ) }
+        if ( OP == 46 ) { REP16 ( F_MULK ) }
+        if ( OP == 47 ) { REP16 ( I_CMPS ) }
+        if ( OP == 48 ) { REP16 ( I_BFE ) }
+        if ( OP == 49 ) { REP16 ( I_ADDC ) }
     }
     float s = 0; for ( int i = 0; i < 16; ++i ) s += a[i] + ( float ) d[i] + ( float ) q[i] + ( float ) u[i];
     if ( s == 12345.678f ) out[0] = s;
@@ -103,12 +149,12 @@ int main ( int argc, char** argv ) {
     double ghz = p.clockRate * 1e-6;
     printf ( "%s CUs %d clock %.2f GHz\n", p.name, p.multiProcessorCount, ghz );
     float* out; hipMalloc ( &out, 4 );
-    for ( int w : { 1, 2, 4 } ) {
+    for ( int w : { 4 } ) {
 #define R(op, n) run<op> ( n, w, out, ghz, p.multiProcessorCount );
         R ( 0, "v_add_f32" ) R ( 1, "v_mul_f32" ) R ( 2, "v_fma_f32" ) R ( 3, "v_min3_f32" ) R ( 4, "v_rcp_f32" ) R ( 5, "v_sqrt_f32" ) R ( 6, "v_rsq_f32" )
         R ( 7, "v_add_f64" ) R ( 8, "v_mul_f64" ) R ( 9, "v_fma_f64" ) R ( 10, "v_rcp_f64" ) R ( 11, "v_cvt_f64_f32" ) R ( 12, "v_cvt_f32_f64" )
-        R ( 13, "v_mul_lo_u32" ) R ( 14, "v_mul_hi_u32" ) R ( 15, "v_mad_u64_u32" ) R ( 16, "v_add_u32" ) R ( 17, "v_lshl_add_u32" ) R ( 18, "v_cndmask" ) R ( 19, "v_cmp_f32" )
-        R ( 20, "v_mul_u32_u24" ) R ( 21, "v_alignbit" ) R ( 22, "v_lshrrev_b64" ) R ( 23, "v_div_scale" ) R ( 24, "v_div_fixup" ) R ( 25, "v_div_fmas" )
+        R ( 13, "v_mul_lo_u32" ) R ( 14, "v_mul_hi_u32" ) R ( 15, "v_mad_u64_u32" ) R ( 16, "v_add_u32" ) R ( 17, "v_lshl_add_u32" )  R ( 19, "v_cmp_f32" )
+        R ( 20, "v_mul_u32_u24" ) R ( 21, "v_alignbit" ) R ( 22, "v_lshrrev_b64" ) R ( 23, "v_div_scale" ) R ( 24, "v_div_fixup" ) R ( 25, "v_div_fmas" ) R ( 27, "v_pk_mul_f32" ) R ( 28, "v_pk_add_f32" ) R ( 29, "v_pk_fma_f32" ) R ( 30, "v_mov_b32" ) R ( 31, "v_pk_mov_b32" ) R ( 32, "v_sub_f32" ) R ( 33, "v_max_f32" ) R ( 34, "v_cndmask vcc" ) R ( 35, "v_cndmask sgpr" ) R ( 36, "v_min_f32" ) R ( 37, "v_and_b32" ) R ( 38, "v_xor_b32" ) R ( 39, "v_lshlrev_b32" ) R ( 40, "v_lshrrev_b32" ) R ( 41, "v_add3_u32" ) R ( 42, "v_sub_u32" ) R ( 43, "v_med3_f32" ) R ( 44, "v_cvt_f32_u32" ) R ( 45, "v_fmac_f32" ) R ( 46, "v_mul_f32 lit" ) R ( 47, "v_cmp e64 sgpr" ) R ( 48, "v_bfe_u32" ) R ( 49, "v_addc_co_u32" )
     }
     return 0;
 }
