@@ -57,24 +57,33 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     const int tid = threadIdx.x;
     Tracer T;
     T.sc = sc;
-    int* words = reinterpret_cast<int*> ( lds );
+    // [staged nodes][staged triangles][staged properties][stack][leaf list][parked words]  (sizes: terra_lds_bytes)
+    float4* ln = lds;                                                // byte offset 0: a staged node's address is its stack word
+    float4* lt = ln + ( TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;
+    float4* lp = lt + 3 * lds_tris;
+    int* words = reinterpret_cast<int*> ( lp + 4 * lds_tris );
     T.stack = words + tid;
-    T.leaves = words + stack_depth * 256 + tid;
-    T.stride = 256;
+    T.leaves = words + stack_depth * TERRA_COL + tid;
     T.leaf_cap = ( int ) leaf_cap;
     T.stack_cap = ( int ) stack_depth - TERRA_CHECK_SHRINK;      // TERRA_CHECK_SHRINK > 0: positive control of the bounds check
     T.faults = nullptr;
     T.cull = cull;
-    float4* stage = lds + ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 64;
-    float4* ln = stage;
-    float4* lt = ln + 4 * lds_nodes;
-    float4* lp = lt + 3 * lds_tris;
     const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
     const float4* gt = reinterpret_cast<const float4*> ( sc.tris );
     const float4* gp = reinterpret_cast<const float4*> ( sc.props );
-    for ( uint32_t i = tid; i < 4 * lds_nodes; i += 256 ) ln[i] = gn[i];
-    for ( uint32_t i = tid; i < 3 * lds_tris; i += 256 ) lt[i] = gt[i];
-    for ( uint32_t i = tid; i < 4 * lds_tris; i += 256 ) lp[i] = gp[i];
+    for ( uint32_t i = tid; i < lds_nodes; i += TERRA_COL ) {       // node i -> the axis-major, both-signs layout (trace_device.h "Staged node")
+        const float4 q0 = gn[4 * i], q1 = gn[4 * i + 1], q2 = gn[4 * i + 2], q3 = gn[4 * i + 3];
+        const float mn0[3] = { q0.x, q0.y, q0.z }, mx0[3] = { q0.w, q1.x, q1.y }, mn1[3] = { q1.z, q1.w, q2.x }, mx1[3] = { q2.y, q2.z, q2.w };
+        float4* o = ln + ( TERRA_LDS_NODE_BYTES / 16 ) * i;
+        #pragma unroll
+        for ( int a = 0; a < 3; ++a ) { o[2 * a] = make_float4 ( mn0[a], mx0[a], mn1[a], mx1[a] ); o[2 * a + 1] = make_float4 ( mx0[a], mn0[a], mx1[a], mn1[a] ); }
+        uint32_t c0 = __float_as_uint ( q3.x ), c1 = __float_as_uint ( q3.y );
+        if ( ! ( c0 & DEV_CHILD_LEAF ) ) c0 *= TERRA_LDS_NODE_BYTES;       // inner child: byte offset of its staged node
+        if ( ! ( c1 & DEV_CHILD_LEAF ) ) c1 *= TERRA_LDS_NODE_BYTES;
+        o[6] = make_float4 ( __uint_as_float ( c0 ), __uint_as_float ( c1 ), 0.f, 0.f );
+    }
+    for ( uint32_t i = tid; i < 3 * lds_tris; i += TERRA_COL ) lt[i] = gt[i];
+    for ( uint32_t i = tid; i < 4 * lds_tris; i += TERRA_COL ) lp[i] = gp[i];
     T.l_nodes = ln; T.l_tris = reinterpret_cast<const float*> ( lt ); T.l_props = lp;
     T.lds_nodes = lds_nodes; T.lds_tris = lds_tris;
     __syncthreads();
@@ -176,9 +185,9 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
-struct LaneTraversal { RayState st; Closest best; int top, nleaf; bool traversing, regular; };
-TD LaneTraversal lane_traversal_idle ( const Ray& any_ray ) {
-    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.top = 0; t.nleaf = 0; t.traversing = false; t.regular = true;
+struct LaneTraversal { RayState st; SlabSel sel; Closest best; int top; bool traversing, regular; };     // top: entries on the lane's stack (its leaf list is always empty between calls)
+TD LaneTraversal lane_traversal_idle ( const Tracer& T, const Ray& any_ray ) {
+    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.top = 0; t.traversing = false; t.regular = true;
     return t;
 }
 // puts `ray` in flight: the origin offset terra_scene_raycast applies (src/Terra.c:1629-1630), ray state, empty closest hit, root on the stack
@@ -186,9 +195,10 @@ template <int COUNT>
 TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     t.st = ray_state_init ( r );
+    t.sel = slab_sel ( r );
     t.regular = ray_is_regular ( r );
     t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu;
-    T.stack[0] = 0; t.top = 1; t.nleaf = 0;
+    *T.stack = 0; t.top = 1;
     t.traversing = true;
     if ( COUNT ) ++c.rays;
 }
@@ -201,8 +211,10 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
     const int exit_active = n_trav - quota;
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
-    if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.st, o_perm, t.best, t.top, t.nleaf, t.traversing, exit_active, c );
-    else traverse_resume<COUNT, MODE, false> ( T, r, t.st, o_perm, t.best, t.top, t.nleaf, t.traversing, exit_active, c );
+    int* sp = T.stack + t.top * TERRA_COL;
+    if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
+    else traverse_resume<COUNT, MODE, false> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
+    t.top = ( int ) ( sp - T.stack ) / TERRA_COL;
     return true;
 }
 
@@ -240,7 +252,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     Counters c = counters_zero();
 
-    float* acc_lds = reinterpret_cast<float*> ( lds_f4 ) + ( p.stack_depth + p.leaf_cap ) * 256 + tid;     // acc.x/y/z at [0], [256], [512]
+    float* acc_lds = reinterpret_cast<float*> ( T.stack - tid ) + ( p.stack_depth + p.leaf_cap ) * TERRA_COL + tid;     // the parked words follow the leaf list: acc.x/y/z at [0], [256], [512]
     acc_lds[0] = 0.f; acc_lds[256] = 0.f; acc_lds[512] = 0.f;
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     Ray ray = make_ray ( v3 ( 0, 0, 0 ), v3 ( 0, 0, 1 ) );
@@ -250,7 +262,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     if constexpr ( TERRA_DECOUPLED_MIS ( INTEGRATOR, MODE, KINDS ) ) {
         // Decoupled loop for Direct + MIS: like the Direct one below with two shadow jobs per shaded hit, in the reference's
         // order -- A: the ray to the light sample, B: the BSDF-sampled ray (mis_prepare / mis_finish_b).
-        LaneTraversal lt = lane_traversal_idle ( ray );
+        LaneTraversal lt = lane_traversal_idle ( T, ray );
         int job = 0;                                             // 0 path segment, 1 shadow ray A, 2 shadow ray B
         bool done = !valid, have_ray = false, cont = false;
         MisPending pend; pend.a_vis = pend.a_hid = pend.f2 = pend.p = pend.t_before = v3 ( 0, 0, 0 ); pend.expected = 0; pend.bpdf2 = pend.cos2 = 0.f; pend.light_object = 0;
@@ -312,7 +324,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // shadow test (direct_prepare), samples the BSDF and plays Russian roulette -- all stream draws in the reference's
         // order -- parks the continuation ray and sends the shadow ray; when that returns, the matching outcome is added
         // and the continuation (or the pixel's next sample) starts. Same rays, same draws, same sums as integrate_direct.
-        LaneTraversal lt = lane_traversal_idle ( ray );
+        LaneTraversal lt = lane_traversal_idle ( T, ray );
         bool done = !valid, have_ray = false, shadow = false, cont = false;
         DirectPending pend; pend.vis = pend.hid = v3 ( 0, 0, 0 ); pend.expected = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 );
@@ -361,7 +373,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // the lanes that entered it have finished; those are shaded and handed their next ray (continuation or the
         // pixel's next camera sample) while the others keep their traversal state. Per pixel nothing changes: same
         // rays, same stream draws, same accumulation order.
-        LaneTraversal lt = lane_traversal_idle ( ray );
+        LaneTraversal lt = lane_traversal_idle ( T, ray );
         bool done = !valid, have_ray = false;
         for ( ;; ) {
             if ( !lt.traversing && !done ) {
@@ -458,11 +470,13 @@ static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank
 }
 
 size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
-    return ( size_t ) ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) lds_nodes * 64 + ( size_t ) lds_tris * ( 48 + 64 );
+    return ( size_t ) ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) lds_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) lds_tris * ( 48 + 64 );
 }
 
-// LDS plan. Small scenes (whole scene <= budget): stage everything; with the Cornell box that is
-// 30.5 KB per block, so the 5 blocks/CU the Simple kernel's registers allow stay resident.
+// LDS plan. Small scenes (whole scene + stack + a leaf list of at least TERRA_LEAF_CAP_RESIDENT_MIN entries <= budget): stage
+// everything; with the Cornell box that is 31.9 KB per block (112-B staged nodes, 14-entry leaf list), so the 5 blocks/CU the
+// Simple kernel's registers allow stay resident. The leaf list takes what the budget leaves, up to 16 entries: a list that
+// fills is drained and the node loop resumes, so its length only decides how often that happens.
 // Large scenes: nothing is staged -- their node fetches are bound by the L1 tag rate of divergent
 // 16-byte loads (each lane its own 64-B node) and by latency, so resident blocks matter most: the
 // leaf list takes what is left of the CU's 160 KB after fitting as many blocks as possible while
@@ -477,17 +491,24 @@ size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_n
 #ifndef TERRA_LDS_BUDGET
 #define TERRA_LDS_BUDGET ( 32 * 1024 )
 #endif
-bool terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack ) {
+#ifndef TERRA_LEAF_CAP_RESIDENT_MIN
+#define TERRA_LEAF_CAP_RESIDENT_MIN 8
+#endif
+// leaf-list entries an LDS-resident plan can afford (0 = the scene does not fit)
+static uint32_t resident_leaf_cap ( uint32_t n_nodes, uint32_t n_tris, int max_stack ) {
     const uint32_t depth = max_stack < 1 ? 1u : ( uint32_t ) max_stack;
-    return ( size_t ) ( depth + TERRA_LEAF_CAP_MAX + TERRA_AUX_WORDS ) * 1024 + ( size_t ) n_nodes * 64 + ( size_t ) n_tris * 112 <= ( size_t ) TERRA_LDS_BUDGET;
+    const size_t fixed = ( size_t ) ( depth + TERRA_AUX_WORDS ) * 1024 + ( size_t ) n_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) n_tris * 112;
+    if ( fixed + ( size_t ) TERRA_LEAF_CAP_RESIDENT_MIN * 1024 > ( size_t ) TERRA_LDS_BUDGET ) return 0;
+    const uint32_t cap = ( uint32_t ) ( ( ( size_t ) TERRA_LDS_BUDGET - fixed ) / 1024 );
+    return cap > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : cap;
 }
+bool terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack ) { return resident_leaf_cap ( n_nodes, n_tris, max_stack ) != 0; }
 void terra_plan_lds ( DevRenderParams& p ) {
-    const size_t budget = TERRA_LDS_BUDGET;
     uint32_t depth = p.scene.max_stack < 1 ? 1u : ( uint32_t ) p.scene.max_stack;
     p.stack_depth = depth;
     p.leaf_cap = TERRA_LEAF_CAP_MAX;
-    if ( terra_scene_fits_lds ( p.scene.n_nodes, p.scene.n_tris, p.scene.max_stack ) ) {
-        p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris;
+    if ( const uint32_t cap = resident_leaf_cap ( p.scene.n_nodes, p.scene.n_tris, p.scene.max_stack ) ) {
+        p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris; p.leaf_cap = cap;
         return;
     }
     p.lds_mode = 0; p.lds_nodes = 0; p.lds_tris = 0;

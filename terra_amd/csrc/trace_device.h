@@ -206,15 +206,26 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 // -----------------------------------------------------------------------------
 // Tracer: where a thread finds the scene and its traversal scratch.
 //
-// LDS layout of a block (DESIGN.md "LDS"): [node stack: stack_depth x 256 ints]
-// [leaf list: leaf_cap x 256 ints] [staged nodes: lds_nodes x 64 B]
-// [per-thread parked words] [staged triangles: lds_tris x 48 B] [staged vertex properties: lds_tris x 64 B].
-// Stack and leaf list are indexed [entry][thread] so the 64 lanes of a wave touch
-// 64 consecutive words (conflict free). Device node numbering is breadth first, so
-// the staged prefix [0, lds_nodes) is the top of the tree; triangles are staged only
-// when the whole soup fits.
+// LDS layout of a block (DESIGN.md "LDS"): [staged nodes: lds_nodes x 112 B] [staged triangles: lds_tris x 48 B]
+// [staged vertex properties: lds_tris x 64 B] [node stack: stack_depth x 256 ints] [leaf list: leaf_cap x 256 ints]
+// [per-thread parked words]. Stack and leaf list are indexed [entry][thread] so the 64 lanes of a wave touch
+// 64 consecutive words (conflict free); a lane walks its column with a pointer (one add per push / pop).
+// Nodes and triangles are staged only when the whole scene fits.
+//
+// Staged node (MODE 1), 7 x 16 B, "axis major, both signs":
+//     [x+] min0.x max0.x min1.x max1.x     [x-] max0.x min0.x max1.x min1.x
+//     [y+] ...                             [y-] ...
+//     [z+] ...                             [z-] ...
+//     [children] child0 child1 - -         (an inner child = the BYTE OFFSET of its staged node, a leaf = DEV_CHILD_LEAF | triangle)
+// A ray whose inverse direction is finite and non-zero on every axis reads, per axis, the copy that matches the sign of its
+// direction (SlabSel): the four floats are then (near plane, far plane) of child 0 and of child 1, so the slab test needs no
+// per-axis min/max at all -- v_min/v_max_f32 issue at 0.57 G/s per SIMD on gfx950 against 0.96 for v_sub/v_mul_f32
+// (profiles/r02_measurements/valu_rates.log). Picking the plane by the sign is exactly min(t1, t2) / max(t1, t2): for
+// bmin <= bmax, (b - o) * inv is monotone in b (both roundings are), increasing for inv > 0 and decreasing for inv < 0.
 // -----------------------------------------------------------------------------
 #define TERRA_LEAF_CAP_MAX 16
+#define TERRA_COL 256              // stride of a stack / leaf-list column: the block's thread count
+#define TERRA_LDS_NODE_BYTES 112   // staged node (see above)
 
 struct Tracer {
     DevScene      sc;
@@ -224,7 +235,6 @@ struct Tracer {
     uint32_t      lds_nodes, lds_tris;
     int*          stack;       // this thread's column
     int*          leaves;
-    int           stride;      // 256
     int           leaf_cap;    // entries in the leaf list (>= 2)
     int           stack_cap;   // entries in the stack column (TERRA_CHECK_BOUNDS builds verify every push against it)
     unsigned long long* faults;
@@ -316,39 +326,72 @@ struct Closest { float depth; uint32_t tri; };
 #ifndef TERRA_CHECK_BOUNDS
 #define TERRA_CHECK_BOUNDS 0
 #endif
-#define TERRA_PUSH(T, top, v) do { if ( TERRA_CHECK_BOUNDS && ( top ) >= ( T ).stack_cap ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { ( T ).stack[ ( top ) * ( T ).stride] = ( int ) ( v ); ++( top ); } } while ( 0 )
-#define TERRA_LEAF(T, n, v) do { if ( TERRA_CHECK_BOUNDS && ( n ) >= ( T ).leaf_cap ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { ( T ).leaves[ ( n ) * ( T ).stride] = ( int ) ( v ); ++( n ); } } while ( 0 )
+#define TERRA_PUSH(T, sp, v) do { if ( TERRA_CHECK_BOUNDS && ( sp ) >= ( T ).stack + ( T ).stack_cap * TERRA_COL ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { *( sp ) = ( int ) ( v ); ( sp ) += TERRA_COL; } } while ( 0 )
+#define TERRA_LEAF(T, lp, v) do { if ( TERRA_CHECK_BOUNDS && ( lp ) >= ( T ).leaves + ( T ).leaf_cap * TERRA_COL ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { *( lp ) = ( int ) ( v ); ( lp ) += TERRA_COL; } } while ( 0 )
 
-// one node of the reference traversal (src/TerraBVH.c:262-303): pop, slab-test both child boxes, push the inner children
-// that are hit, append the leaf children to the lane's list (all of them; with Tracer::cull only those whose box is hit)
-template <int COUNT, int MODE, bool FAST>
-TD void node_step ( const Tracer& T, const Ray& r, int& top, int& nleaf, Counters& c ) {
-    const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
-    PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
-    uint32_t ni = ( uint32_t ) T.stack[ ( --top ) * T.stride];
-    float4 q0, q1, q2, q3;
-    if ( MODE == 1 ) { q0 = T.l_nodes[4 * ni]; q1 = T.l_nodes[4 * ni + 1]; q2 = T.l_nodes[4 * ni + 2]; q3 = T.l_nodes[4 * ni + 3]; }
-    else { q0 = g_nodes[4 * ni]; q1 = g_nodes[4 * ni + 1]; q2 = g_nodes[4 * ni + 2]; q3 = g_nodes[4 * ni + 3]; }
-    uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
-    if ( COUNT ) ++c.nodes;
-    bool hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
-    bool hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
-    bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
-    if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, top, child0 ); }
-    if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, top, child1 ); }
-    const bool met0 = leaf0 && child0 != DEV_CHILD_EMPTY, met1 = leaf1 && child1 != DEV_CHILD_EMPTY;
-    if ( met0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child0 & 0x7fffffffu ) ); }
-    if ( met1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, nleaf, ( child1 & 0x7fffffffu ) ); }
-    if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( met0 && !hit0 ) + ( uint32_t ) ( met1 && !hit1 );
+// which copy of each axis a lane reads from a staged node (byte offsets inside the node); regular rays only
+struct SlabSel { uint32_t x, y, z; };
+TD SlabSel slab_sel ( const Ray& r ) {
+    SlabSel s;
+    s.x = r.inv.x < 0.f ? 16u : 0u; s.y = r.inv.y < 0.f ? 48u : 32u; s.z = r.inv.z < 0.f ? 80u : 64u;
+    return s;
+}
+// slab test from (near, far) planes per axis: what slab<true> computes, without the per-axis min / max
+TD bool slab_near_far ( float nx, float fx, float ny, float fy, float nz, float fz, const Ray& r ) {
+    float tnx = ( nx - r.o.x ) * r.inv.x, tfx = ( fx - r.o.x ) * r.inv.x;
+    float tny = ( ny - r.o.y ) * r.inv.y, tfy = ( fy - r.o.y ) * r.inv.y;
+    float tnz = ( nz - r.o.z ) * r.inv.z, tfz = ( fz - r.o.z ) * r.inv.z;
+    float tmin = __builtin_fmaxf ( __builtin_fmaxf ( tnx, tny ), tnz );
+    float tmax = __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz );
+    return tmax > __builtin_fmaxf ( tmin, 0.f );
 }
 
-// triangle test of entry i of the lane's leaf list, in the order the leaves were met: strict "<" keeps the first of equal depths
+// one node of the reference traversal (src/TerraBVH.c:262-303): pop, slab-test both child boxes, push the inner children
+// that are hit, append the leaf children to the lane's list (all of them; with Tracer::cull only those whose box is hit).
+// An empty child slot (scenes with < 2 triangles) travels as a leaf and is dropped by leaf_step.
+template <int COUNT, int MODE, bool FAST>
+TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp, int*& lp, Counters& c ) {
+    PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
+    sp -= TERRA_COL;
+    const uint32_t w = ( uint32_t ) * sp;
+    uint32_t child0, child1; bool hit0, hit1;
+    if ( MODE == 1 ) {
+        const char* node = reinterpret_cast<const char*> ( T.l_nodes ) + w;          // w = byte offset of the staged node
+        const uint2 cw = *reinterpret_cast<const uint2*> ( node + 96 );
+        child0 = cw.x; child1 = cw.y;
+        if ( FAST ) {
+            const float4 ax = *reinterpret_cast<const float4*> ( node + sel.x ), ay = *reinterpret_cast<const float4*> ( node + sel.y ), az = *reinterpret_cast<const float4*> ( node + sel.z );
+            hit0 = slab_near_far ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r );
+            hit1 = slab_near_far ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r );
+        } else {
+            const float4 ax = *reinterpret_cast<const float4*> ( node ), ay = *reinterpret_cast<const float4*> ( node + 32 ), az = *reinterpret_cast<const float4*> ( node + 64 );
+            hit0 = slab<false> ( v3 ( ax.x, ay.x, az.x ), v3 ( ax.y, ay.y, az.y ), r );
+            hit1 = slab<false> ( v3 ( ax.z, ay.z, az.z ), v3 ( ax.w, ay.w, az.w ), r );
+        }
+    } else {
+        const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
+        const float4 q0 = g_nodes[4 * w], q1 = g_nodes[4 * w + 1], q2 = g_nodes[4 * w + 2], q3 = g_nodes[4 * w + 3];
+        child0 = __float_as_uint ( q3.x ); child1 = __float_as_uint ( q3.y );
+        hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
+        hit1 = slab<FAST> ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r );
+    }
+    if ( COUNT ) ++c.nodes;
+    const bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
+    if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, sp, child0 ); }
+    if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, sp, child1 ); }
+    if ( leaf0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child0 & 0x7fffffffu ) ); }
+    if ( leaf1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child1 & 0x7fffffffu ) ); }
+    if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( leaf0 && !hit0 ) + ( uint32_t ) ( leaf1 && !hit1 );
+}
+
+// triangle test of one entry of the lane's leaf list, in the order the leaves were met: strict "<" keeps the first of equal depths
 template <int COUNT, int MODE>
-TD void leaf_step ( const Tracer& T, int i, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
+TD void leaf_step ( const Tracer& T, const int* entry, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
     const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
     const int kx = st.ix, ky = st.iy, kz = st.iz;
     PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
-    uint32_t ti = ( uint32_t ) T.leaves[i * T.stride];
+    const uint32_t ti = ( uint32_t ) * entry;
+    if ( ti == ( DEV_CHILD_EMPTY & 0x7fffffffu ) ) return;           // the empty slot of a degenerate tree
     float pa[3], pb[3], pc[3];
     if ( MODE == 1 ) {
         const float* t = T.l_tris + 12 * ti;
@@ -369,14 +412,16 @@ TD void leaf_step ( const Tracer& T, int i, const RayState& st, V3 o_perm, Close
 
 template <int COUNT, int MODE, bool FAST>
 TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
-    int top = 1, nleaf = 0;
-    T.stack[0] = 0;
+    const SlabSel sel = slab_sel ( r );
+    int* sp = T.stack; int* lp = T.leaves;
+    int* const lp_full = T.leaves + ( T.leaf_cap - 2 ) * TERRA_COL;       // a node adds at most two leaves
+    *sp = 0; sp += TERRA_COL;                                          // the root: node 0 = byte offset 0
     for ( ;; ) {
         PS_WAVE ( c, kPsDrainIter );
-        while ( top > 0 && nleaf <= T.leaf_cap - 2 ) node_step<COUNT, MODE, FAST> ( T, r, top, nleaf, c );
-        for ( int i = 0; i < nleaf; ++i ) leaf_step<COUNT, MODE> ( T, i, st, o_perm, best, c );
-        nleaf = 0;
-        if ( top <= 0 ) break;
+        while ( sp != T.stack && lp <= lp_full ) node_step<COUNT, MODE, FAST> ( T, r, sel, sp, lp, c );
+        for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) leaf_step<COUNT, MODE> ( T, e, st, o_perm, best, c );
+        lp = T.leaves;
+        if ( sp == T.stack ) break;
     }
 }
 
@@ -421,12 +466,13 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
     ClosestRanked best; best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-    int top = 1;
-    T.stack[0] = 0;
+    int* top = T.stack;
+    *top = 0; top += TERRA_COL;
     for ( ;; ) {
         uint32_t leaf = 0;
-        while ( top > 0 ) {
-            uint32_t w = ( uint32_t ) T.stack[ ( --top ) * T.stride];
+        while ( top != T.stack ) {
+            top -= TERRA_COL;
+            uint32_t w = ( uint32_t ) * top;
             if ( w & DEV_CHILD_LEAF ) { leaf = w; break; }
             float4 q0 = nodes[4 * w], q1 = nodes[4 * w + 1], q2 = nodes[4 * w + 2], q3 = nodes[4 * w + 3];
             uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
@@ -474,17 +520,19 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
 // `traversing` is cleared for lanes whose traversal completed.
 // -----------------------------------------------------------------------------
 template <int COUNT, int MODE, bool FAST>
-TD void traverse_resume ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, int& top, int& nleaf, bool& traversing, int exit_active, Counters& c ) {
+TD void traverse_resume ( const Tracer& T, const Ray& r, const SlabSel& sel, const RayState& st, V3 o_perm, Closest& best, int*& sp, bool& traversing, int exit_active, Counters& c ) {
+    int* const lp_full = T.leaves + ( T.leaf_cap - 2 ) * TERRA_COL;
+    int* lp = T.leaves;                                      // every lane's list is empty on entry and on exit
     for ( ;; ) {
         for ( ;; ) {
-            const bool can = traversing && top > 0 && nleaf <= T.leaf_cap - 2;
-            const int n_can = __popcll ( __ballot ( can ) ), n_nodes = __popcll ( __ballot ( traversing && top > 0 ) );
+            const bool can = traversing && sp != T.stack && lp <= lp_full;
+            const int n_can = __popcll ( __ballot ( can ) ), n_nodes = __popcll ( __ballot ( traversing && sp != T.stack ) );
             if ( n_can == 0 || n_nodes <= exit_active ) break;
-            if ( can ) node_step<COUNT, MODE, FAST> ( T, r, top, nleaf, c );
+            if ( can ) node_step<COUNT, MODE, FAST> ( T, r, sel, sp, lp, c );
         }
-        for ( int i = 0; i < nleaf; ++i ) leaf_step<COUNT, MODE> ( T, i, st, o_perm, best, c );         // lanes that are not traversing hold nleaf == 0
-        nleaf = 0;
-        if ( traversing && top <= 0 ) traversing = false;
+        for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) leaf_step<COUNT, MODE> ( T, e, st, o_perm, best, c );        // lanes that are not traversing hold an empty list
+        lp = T.leaves;
+        if ( traversing && sp == T.stack ) traversing = false;
         if ( __popcll ( __ballot ( traversing ) ) <= exit_active ) break;
     }
 }

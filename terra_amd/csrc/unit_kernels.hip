@@ -78,7 +78,7 @@ hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, c
 // unit kernels read the scene from global memory (MODE 0); LDS only holds stack + leaf list
 __device__ __forceinline__ Tracer unit_tracer ( const DevScene& sc, int* lds ) {
     Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.lds_nodes = 0; T.lds_tris = 0;
-    T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.stride = 256; T.leaf_cap = TERRA_LEAF_CAP_MAX;
+    T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.leaf_cap = TERRA_LEAF_CAP_MAX;
     T.stack_cap = sc.max_stack < 1 ? 1 : sc.max_stack; T.faults = nullptr; T.cull = false;      // unit level: the reference's traversal decision by decision       // (unit kernels are not built with TERRA_CHECK_BOUNDS)
     return T;
 }
