@@ -34,6 +34,15 @@ typedef enum {
    void in the reference API (include/Terra.h:229), so this is its side channel. */
 const char* terra_amd_last_error ( void );
 void        terra_amd_clear_error ( void );
+/* Process-wide companion: the FIRST error any thread has recorded since the last terra_amd_clear_first_error(), copied into buf
+   (capacity bytes, always terminated); returns its TerraAmdStatus, 0 if there is none. For clients whose worker threads call
+   terra_render() while another thread polls for completion, as the reference's does (satellite/src/Renderer.cpp:70-98,118-157):
+   the per-thread channel above never shows a worker's failure to the polling thread. */
+int         terra_amd_first_error ( char* buf, size_t capacity );
+void        terra_amd_clear_first_error ( void );
+/* Bytes of device staging memory the calling thread holds for terra_render() on host framebuffers: 28 B per pixel of the largest
+   tile it has rendered (not of the frame). Released, with the thread's stream, when the thread exits. */
+size_t      terra_amd_thread_staging_bytes ( void );
 
 /* Device selection for subsequent commits/renders issued by this thread's
    scenes. One process drives one GPU in the multi-GPU layout. */
@@ -65,6 +74,7 @@ int  terra_amd_get_tree_mode ( HTerraScene scene );
 typedef struct {
     int   tree_mode;                /* as set */
     int   fast_tree;                /* 1: the fast tree is used */
+    int   fast_tree_built_on_device;/* 1: ... and was built on the GPU (terra_amd_set_tree_builder) */
     int   leaf_cull;                /* 1: reference tree with the leaf-box cull */
     int   lds_resident;             /* 1: the whole scene (nodes, triangles, vertex properties) is staged in LDS by every block */
     float max_coordinate;           /* largest |vertex coordinate| of the committed scene */
@@ -72,6 +82,12 @@ typedef struct {
     char  note[192];                /* the reason, in words */
 } TerraAmdTraversalInfo;
 int  terra_amd_traversal_info ( HTerraScene scene, TerraAmdTraversalInfo* out );
+/* Who builds the fast tree at commit (replaces src/TerraBVH.c:128-244 for that tree): 0 (default) = the host, 3-axis binned SAH;
+   1 = the GPU, a linear BVH (Morton sort + Karras hierarchy + bottom-up fit) built from the triangle soup already in HBM in a few
+   milliseconds. Same node format, same traversal kernel, same image; the LBVH visits more nodes per ray than the SAH tree. The
+   reference tree -- needed for the visit ranks that break depth ties, and for replica traversal -- is built on the host either way. */
+int  terra_amd_set_tree_builder ( HTerraScene scene, int builder );
+int  terra_amd_get_tree_builder ( HTerraScene scene );
 
 /* Sample split: how many lanes share one pixel. With split = S (1, 2, 4, 8 or 16; default 1) a render call of
    spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random

@@ -16,7 +16,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libterra_amd.so"
-SOURCES = ["scene_host.cpp", "tree_build.cpp", "render_kernels.hip", "unit_kernels.hip"]
+SOURCES = ["scene_host.cpp", "tree_build.cpp", "render_kernels.hip", "unit_kernels.hip", "tree_build_device.hip"]
 HEADERS = ["dev_types.h", "dev_math.h", "rng.h", "trace_device.h", "sampling_device.h", "kernels.h", "tree_build.h"]
 ARCH = os.environ.get("TERRA_AMD_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

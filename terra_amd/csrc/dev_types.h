@@ -130,6 +130,9 @@ struct DevRenderParams {
     float    gamma;
     uint32_t fb_w, fb_h;
     uint32_t x, y, w, h;            // rectangle to render
+    // where pixel (px, py) of the frame lives in `pixels` / `results` / `rand_calls`: element (py - st_y) * st_pitch + (px - st_x).
+    // Device-resident frames: st_x = st_y = 0, st_pitch = fb_w; terra_render() on a host frame stages the rectangle only.
+    uint32_t st_x, st_y, st_pitch;
     uint32_t tile_size, rank, world; // sharding: tiles t with t % world == rank (world == 1: everything)
     uint32_t spp;                   // effective samples per pixel (after the stratified round-up)
     // sample split (terra_amd_set_sample_split): the call's spp samples are cut into `split` = 2^split_log2 chunks

@@ -110,7 +110,7 @@ TD bool block_pixel ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint
 __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams p ) {
     uint32_t px, py;
     if ( !block_pixel ( p, blockIdx.x, threadIdx.x, px, py ) ) return;
-    const size_t pix = ( size_t ) py * p.fb_w + px;
+    const size_t pix = ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x );
     DevResult* results = reinterpret_cast<DevResult*> ( p.results );
     DevResult out = results[pix];
     uint32_t calls = 0;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
 
     DevResult* results = reinterpret_cast<DevResult*> ( p.results );
     // only the sample count is needed up front (it keys the streams); the running sum is re-read at the end
-    const int prior_samples = valid ? results[ ( size_t ) py * p.fb_w + px].samples : 0;
+    const int prior_samples = valid ? results[ ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x )].samples : 0;
     PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     Counters c = counters_zero();
 
@@ -435,7 +435,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     if ( p.split > 1 ) {      // this chunk's sum; terra_resolve_kernel folds the chunks into the pixel in order
         p.partials[ ( ( size_t ) chunk * ( gridDim.x >> p.split_log2 ) + blk ) * 256 + tid] = make_float4 ( acc_lds[0], acc_lds[256], acc_lds[512], __uint_as_float ( COUNT == 2 ? c.rand_calls : 0u ) );
     } else if ( valid ) {
-        const size_t pix = ( size_t ) py * p.fb_w + px;
+        const size_t pix = ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x );
         const DevResult prior = results[pix];
         DevResult out;
         out.acc[0] = acc_lds[0] + prior.acc[0]; out.acc[1] = acc_lds[256] + prior.acc[1]; out.acc[2] = acc_lds[512] + prior.acc[2];

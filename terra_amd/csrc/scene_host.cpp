@@ -33,11 +33,21 @@
 // error channel
 // ------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
+// process-wide: the FIRST error any thread recorded since the last terra_amd_clear_first_error(). terra_render() is void and the
+// reference's client calls it from worker threads while the main thread polls (satellite/src/Renderer.cpp:70-98,118-157):
+// the per-thread channel alone would never show a worker's failure to the thread that looks.
+static std::mutex g_first_error_mutex;
+static std::string g_first_error;
+static int g_first_error_status = 0;
 
 static int fail ( TerraAmdStatus st, const char* fmt, ... ) {
     char buf[512];
     va_list a; va_start ( a, fmt ); vsnprintf ( buf, sizeof buf, fmt, a ); va_end ( a );
     g_last_error = buf;
+    {
+        std::lock_guard<std::mutex> lock ( g_first_error_mutex );
+        if ( g_first_error.empty() ) { g_first_error = buf; g_first_error_status = ( int ) st; }
+    }
     fprintf ( stderr, "[terra_amd] error: %s\n", buf );
     return ( int ) st;
 }
@@ -45,6 +55,15 @@ static int fail ( TerraAmdStatus st, const char* fmt, ... ) {
 
 extern "C" const char* terra_amd_last_error ( void ) { return g_last_error.c_str(); }
 extern "C" void terra_amd_clear_error ( void ) { g_last_error.clear(); }
+extern "C" int terra_amd_first_error ( char* buf, size_t capacity ) {
+    std::lock_guard<std::mutex> lock ( g_first_error_mutex );
+    if ( buf && capacity ) snprintf ( buf, capacity, "%s", g_first_error.c_str() );
+    return g_first_error.empty() ? 0 : g_first_error_status;
+}
+extern "C" void terra_amd_clear_first_error ( void ) {
+    std::lock_guard<std::mutex> lock ( g_first_error_mutex );
+    g_first_error.clear(); g_first_error_status = 0;
+}
 
 // ------------------------------------------------------------------------------
 // device selection
@@ -243,6 +262,8 @@ struct Scene {
     // leaf-box cull when they are LDS-resident and the fast tree otherwise; scenes that fail it run as mode 0 (the reason is kept in tree_note)
     int tree_mode = 2;
     bool use_fast = false;              // what the last upload decided
+    int tree_builder = 0;               // terra_amd_set_tree_builder: 0 = host (binned SAH), 1 = device (LBVH, tree_build_device.hip)
+    bool fast_on_device = false;        // the fast tree of the last upload was built on the device
     bool cull_ok = false;               // leaf-box cull allowed for this scene (subject to the per-call camera check)
     float coord_max = 0.f;              // largest |coordinate| of any vertex
     std::string tree_note;              // why the automatic mode chose what it chose
@@ -290,12 +311,19 @@ extern "C" int terra_amd_set_tree_mode ( HTerraScene h, int mode ) {
     return 0;
 }
 extern "C" int terra_amd_get_tree_mode ( HTerraScene h ) { return S ( h )->tree_mode; }
+extern "C" int terra_amd_set_tree_builder ( HTerraScene h, int builder ) {
+    if ( builder != 0 && builder != 1 ) return fail ( kTerraAmdErrBadArgument, "tree builder %d (0 = host binned SAH, 1 = device LBVH)", builder );
+    Scene* s = S ( h );
+    if ( s->tree_builder != builder ) { s->tree_builder = builder; s->dirty_objects = true; s->committed = false; }
+    return 0;
+}
+extern "C" int terra_amd_get_tree_builder ( HTerraScene h ) { return S ( h )->tree_builder; }
 extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* out ) {
     Scene* s = S ( h );
     if ( !out ) return fail ( kTerraAmdErrBadArgument, "null output" );
     memset ( out, 0, sizeof *out );
     if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "scene not committed" );
-    out->tree_mode = s->tree_mode; out->fast_tree = s->use_fast ? 1 : 0; out->leaf_cull = ( s->cull_ok && !s->use_fast ) ? 1 : 0;
+    out->tree_mode = s->tree_mode; out->fast_tree = s->use_fast ? 1 : 0; out->fast_tree_built_on_device = s->fast_on_device ? 1 : 0; out->leaf_cull = ( s->cull_ok && !s->use_fast ) ? 1 : 0;
     out->lds_resident = ( !s->use_fast && terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), s->dev.n_tris, s->max_stack ) ) ? 1 : 0;
     out->max_coordinate = s->coord_max; out->max_coordinate_allowed = TERRA_CULL_MAX_COORD;
     snprintf ( out->note, sizeof out->note, "%s", s->tree_note.c_str() );
@@ -387,7 +415,7 @@ static bool verify_reference_leaf_boxes ( const Scene* s, std::string& why ) {
     return true;
 }
 // every child box of the fast tree contains the boxes of all triangles below it (what its culling relies on)
-static bool verify_fast_tree ( const std::vector<DevNode>& nodes, const std::vector<fastbvh::Prim>& prims_in_leaf_order, std::string& why ) {
+static bool verify_fast_tree ( const std::vector<DevNode>& nodes, const std::vector<TerraAABB>& boxes_in_leaf_order, std::string& why ) {
     if ( nodes.empty() ) return true;
     struct Item { uint32_t node; TerraAABB bound[2]; int stage; };
     // iterative post-order: compute the union of triangle boxes below each child and compare with the stored box
@@ -416,8 +444,8 @@ static bool verify_fast_tree ( const std::vector<DevNode>& nodes, const std::vec
             if ( n.child[c] == DEV_CHILD_EMPTY ) { below[2 * ni + c] = u; continue; }
             if ( n.child[c] & DEV_CHILD_LEAF ) {
                 const uint32_t first = n.child[c] & 0x07ffffffu, cnt = ( ( n.child[c] >> 27 ) & 0xfu ) + 1;
-                if ( ( size_t ) first + cnt > prims_in_leaf_order.size() ) { why = "fast tree: leaf range out of range"; return false; }
-                for ( uint32_t j = 0; j < cnt; ++j ) unite ( u, prims_in_leaf_order[first + j].box );
+                if ( ( size_t ) first + cnt > boxes_in_leaf_order.size() ) { why = "fast tree: leaf range out of range"; return false; }
+                for ( uint32_t j = 0; j < cnt; ++j ) unite ( u, boxes_in_leaf_order[first + j] );
             } else {
                 const uint32_t ch = n.child[c];
                 unite ( u, below[2 * ch] ); unite ( u, below[2 * ch + 1] );
@@ -544,8 +572,8 @@ static int upload_scene ( Scene* s ) {
         }
     }
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
-    std::vector<DevNode> fnodes; std::vector<DevTri> ftris;
-    s->fast_nodes = 0; s->fast_max_stack = 1;
+    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device;
+    s->fast_nodes = 0; s->fast_max_stack = 1; s->fast_on_device = false;
     // traversal policy (see Scene::tree_mode and the containment check above)
     s->coord_max = 0.f; s->cull_ok = false; s->tree_note.clear();
     bool margin_ok = true;
@@ -575,33 +603,42 @@ static int upload_scene ( Scene* s ) {
                 }
             }
         }
-        std::vector<fastbvh::Prim> prims ( ntri );
-        for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count; ++i ) {
-            fastbvh::Prim& q = prims[s->first_tri[j] + i];
-            q.box = bvh::empty_box(); bvh::grow_by_triangle ( q.box, s->objects[j].triangles[i] );
-            q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
-            q.soup = ( uint32_t ) ( s->first_tri[j] + i );
+        s->fast_on_device = s->tree_builder == 1 && ntri > 64 && terra_amd_device_count() > 0;
+        if ( s->fast_on_device ) {
+            // built after the upload, from the soup already in HBM; the host only supplies the reference visit ranks
+            rank_for_device.swap ( rank );
+        } else {
+            std::vector<fastbvh::Prim> prims ( ntri );
+            for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count; ++i ) {
+                fastbvh::Prim& q = prims[s->first_tri[j] + i];
+                q.box = bvh::empty_box(); bvh::grow_by_triangle ( q.box, s->objects[j].triangles[i] );
+                q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
+                q.soup = ( uint32_t ) ( s->first_tri[j] + i );
+            }
+            double t_phase = now_s();
+            fastbvh::Built built = fastbvh::build ( prims );        // (reorders prims into leaf order)
+            phase ( "fast tree (host)", t_phase );
+            std::string why;
+            std::vector<TerraAABB> leaf_boxes ( prims.size() );
+            for ( size_t k = 0; k < prims.size(); ++k ) leaf_boxes[k] = prims[k].box;
+            if ( s->tree_mode == 2 && !verify_fast_tree ( built.nodes, leaf_boxes, why ) ) {       // cannot happen with this builder (plain unions); checked because the culling relies on it
+                s->use_fast = false; s->tree_note = why + ": reference tree";
+                built.nodes.clear(); built.order.clear();
+            }
+            fnodes.swap ( built.nodes );
+            ftris.resize ( ntri ? ntri : 1 );
+            for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
+            s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
         }
-        double t_phase = now_s();
-        fastbvh::Built built = fastbvh::build ( prims );        // (reorders prims into leaf order)
-        phase ( "fast tree (host)", t_phase );
-        std::string why;
-        if ( s->tree_mode == 2 && !verify_fast_tree ( built.nodes, prims, why ) ) {       // cannot happen with this builder (plain unions); checked because the culling relies on it
-            s->use_fast = false; s->tree_note = why + ": reference tree";
-            built.nodes.clear(); built.order.clear();
-        }
-        fnodes.swap ( built.nodes );
-        ftris.resize ( ntri ? ntri : 1 );
-        for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
-        s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
     }
-    if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? "containment verified: fast tree (scene is not LDS-resident)" : "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
+    if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
     // one blob, 256-byte aligned sections
     auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
     size_t o_mats = align ( o_props + props.size() * sizeof ( DevProps ) ), o_lights = align ( o_mats + mats.size() * sizeof ( DevMaterial ) );
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
-    size_t o_ft = align ( o_fn + fnodes.size() * sizeof ( DevNode ) ), o_td = align ( o_ft + ftris.size() * sizeof ( DevTri ) );
+    const size_t fn_cap = s->fast_on_device ? ntri : fnodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();      // a device build writes at most n - 1 nodes, n triangles
+    size_t o_ft = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );
     std::vector<DevTexture> tdesc ( textures.size() );
     std::vector<size_t> tex_off ( textures.size() );
     size_t total = align ( o_td + tdesc.size() * sizeof ( DevTexture ) );
@@ -630,6 +667,32 @@ static int upload_scene ( Scene* s ) {
         HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
+    bool have_fast = !fnodes.empty();
+    if ( s->fast_on_device ) {
+        double t_phase = now_s();
+        uint32_t* d_rank = nullptr;
+        HIP_TRY ( hipMalloc ( ( void** ) &d_rank, ntri * sizeof ( uint32_t ) ), kTerraAmdErrNoDevice );
+        hipError_t e = hipMemcpy ( d_rank, rank_for_device.data(), ntri * sizeof ( uint32_t ), hipMemcpyHostToDevice );
+        uint32_t built_nodes = 0; int built_stack = 1;
+        if ( e == hipSuccess ) e = terra_build_fast_tree_device ( ( const DevTri* ) ( base + o_tris ), d_rank, ( uint32_t ) ntri, ( DevNode* ) ( base + o_fn ), ( DevTri* ) ( base + o_ft ), &built_nodes, &built_stack, nullptr );
+        ( void ) hipFree ( d_rank );
+        if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "device tree build: %s", hipGetErrorString ( e ) );
+        phase ( "fast tree (device LBVH)", t_phase );
+        s->fast_nodes = built_nodes; s->fast_max_stack = built_stack; have_fast = true;
+        if ( s->tree_mode == 2 || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {          // the culling relies on containment: read the tree back and check it like the host-built one
+            std::vector<DevNode> rn ( built_nodes ); std::vector<DevTri> rt ( ntri );
+            HIP_TRY ( hipMemcpy ( rn.data(), base + o_fn, rn.size() * sizeof ( DevNode ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
+            HIP_TRY ( hipMemcpy ( rt.data(), base + o_ft, rt.size() * sizeof ( DevTri ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
+            std::vector<TerraAABB> leaf_boxes ( ntri );
+            for ( size_t k = 0; k < ntri; ++k ) {
+                TerraTriangle t; memcpy ( &t.a, rt[k].a, 12 ); memcpy ( &t.b, rt[k].b, 12 ); memcpy ( &t.c, rt[k].c, 12 );
+                leaf_boxes[k] = bvh::empty_box(); bvh::grow_by_triangle ( leaf_boxes[k], t );
+            }
+            std::string why;
+            if ( !verify_fast_tree ( rn, leaf_boxes, why ) ) return fail ( kTerraAmdErrLaunch, "device tree build: %s", why.c_str() );
+            phase ( "  read back + containment check", t_phase );
+        }
+    }
     for ( size_t k = 0; k < textures.size(); ++k ) {
         const TerraTexture* t = textures[k];
         HIP_TRY ( hipMemcpy ( base + tex_off[k], t->pixels, ( size_t ) t->width * t->height * t->components * t->depth, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
@@ -643,7 +706,7 @@ static int upload_scene ( Scene* s ) {
     s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
     s->dev.n_nodes = ( uint32_t ) nodes.size(); s->dev.n_tris = ( uint32_t ) ntri; s->dev.n_objects = ( uint32_t ) nobj; s->dev.n_lights = ( uint32_t ) s->lights.size();
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
-    s->dev.fast_nodes = fnodes.empty() ? nullptr : ( const DevNode* ) ( base + o_fn ); s->dev.fast_tris = fnodes.empty() ? nullptr : ( const DevTri* ) ( base + o_ft );
+    s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
     s->device_ok = true;
@@ -777,6 +840,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.fb_w = ( uint32_t ) fb_w; p.fb_h = ( uint32_t ) fb_h;
     p.x = ( uint32_t ) x; p.y = ( uint32_t ) y; p.w = ( uint32_t ) w; p.h = ( uint32_t ) h;
     p.tile_size = ( uint32_t ) tile; p.rank = ( uint32_t ) rank; p.world = ( uint32_t ) world;
+    p.st_x = 0; p.st_y = 0; p.st_pitch = ( uint32_t ) fb_w;          // framebuffer arrays indexed like the frame (render_host stages a rectangle instead)
     p.spp = effective_spp ( s->opts );
     p.split = 1; p.split_log2 = 0; p.chunk_spp = p.spp; p.partials = nullptr;
     p.bounces = ( uint32_t ) s->opts.bounces;
@@ -915,18 +979,30 @@ extern "C" int terra_amd_unpack_tiles ( void* d_pixels, void* d_results, size_t 
 }
 
 // ---- terra_render on a HOST framebuffer (the drop-in entry point) -------------------
-// Per calling thread: one stream and a device staging framebuffer the size of the
-// largest framebuffer seen. The tile's running sums go up (they key the random
-// streams and are accumulated on), the kernel renders, the tile comes back.
-struct ThreadSlot { int device = -1; hipStream_t stream = nullptr; void* d_pixels = nullptr; void* d_results = nullptr; size_t cap_px = 0; };
+// Per calling thread: one stream and a device staging buffer the size of the largest TILE the thread has rendered (not of the
+// frame: a client that renders 128-pixel tiles from 8 workers stages 8 x 0.46 MB, not 8 frames). The tile's running sums go up
+// (they key the random streams and are accumulated on), the kernel renders into the staging rectangle, the tile comes back.
+// The slot is released when its thread exits.
+struct ThreadSlot {
+    int device = -1; hipStream_t stream = nullptr; void* d_pixels = nullptr; void* d_results = nullptr; size_t cap_px = 0;
+    void release() {
+        if ( device < 0 ) return;
+        if ( hipSetDevice ( device ) == hipSuccess ) {
+            if ( stream ) { ( void ) hipStreamSynchronize ( stream ); ( void ) hipStreamDestroy ( stream ); }
+            if ( d_pixels ) ( void ) hipFree ( d_pixels );
+            if ( d_results ) ( void ) hipFree ( d_results );
+        }
+        device = -1; stream = nullptr; d_pixels = d_results = nullptr; cap_px = 0;
+    }
+    ~ThreadSlot() { release(); }
+};
 static thread_local ThreadSlot t_slot;
 
 static int slot_prepare ( int device, size_t npx ) {
     ThreadSlot& t = t_slot;
     HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );
     if ( t.device != device ) {
-        if ( t.stream ) { ( void ) hipStreamDestroy ( t.stream ); ( void ) hipFree ( t.d_pixels ); ( void ) hipFree ( t.d_results ); }
-        t = ThreadSlot(); t.device = device;
+        t.release(); t.device = device;
         HIP_TRY ( hipStreamCreateWithFlags ( &t.stream, hipStreamNonBlocking ), kTerraAmdErrNoDevice );
     }
     if ( t.cap_px < npx ) {
@@ -939,26 +1015,27 @@ static int slot_prepare ( int device, size_t npx ) {
     }
     return 0;
 }
+extern "C" size_t terra_amd_thread_staging_bytes ( void ) { return t_slot.cap_px * 28; }
 
 static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t h ) {
     if ( !fb || !fb->pixels || !fb->results ) return fail ( kTerraAmdErrBadArgument, "null framebuffer" );
     DevRenderParams p;
     int rc = fill_params ( s, cam, fb->width, fb->height, x, y, w, h, 64, 0, 1, p );
     if ( rc ) return rc;
-    rc = slot_prepare ( s->device, fb->width * fb->height );
+    rc = slot_prepare ( s->device, w * h );
     if ( rc ) return rc;
     ThreadSlot& t = t_slot;
-    // staging uses the framebuffer's own indexing, so the kernel is the same as for device-resident frames
+    // the staging buffer holds the rectangle only (rows of w pixels); the kernel addresses it through st_x / st_y / st_pitch while
+    // the camera and the random streams keep using the frame's geometry
+    p.st_x = ( uint32_t ) x; p.st_y = ( uint32_t ) y; p.st_pitch = ( uint32_t ) w;
     const size_t rpitch = fb->width * 16, ppitch = fb->width * 12;
-    char* dres = ( char* ) t.d_results + ( y * fb->width + x ) * 16;
-    char* dpix = ( char* ) t.d_pixels + ( y * fb->width + x ) * 12;
     const char* hres = ( const char* ) fb->results + ( y * fb->width + x ) * 16;
     char* hpix = ( char* ) fb->pixels + ( y * fb->width + x ) * 12;
-    HIP_TRY ( hipMemcpy2DAsync ( dres, rpitch, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, t.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipMemcpy2DAsync ( t.d_results, w * 16, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, t.stream ), kTerraAmdErrLaunch );
     p.pixels = ( float* ) t.d_pixels; p.results = t.d_results; p.rand_calls = nullptr;
     if ( int lrc = launch_render ( s, p, t.stream ) ) return lrc;
-    HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, dres, rpitch, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
-    HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, dpix, ppitch, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, t.d_results, w * 16, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, t.d_pixels, w * 12, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipStreamSynchronize ( t.stream ), kTerraAmdErrLaunch );
     account_launch ( s, p );
     return 0;

@@ -36,7 +36,7 @@ class Stats(C.Structure):
 
 
 class TraversalInfo(C.Structure):
-    _fields_ = [("tree_mode", C.c_int), ("fast_tree", C.c_int), ("leaf_cull", C.c_int), ("lds_resident", C.c_int), ("max_coordinate", C.c_float), ("max_coordinate_allowed", C.c_float), ("note", C.c_char * 192)]
+    _fields_ = [("tree_mode", C.c_int), ("fast_tree", C.c_int), ("fast_tree_built_on_device", C.c_int), ("leaf_cull", C.c_int), ("lds_resident", C.c_int), ("max_coordinate", C.c_float), ("max_coordinate_allowed", C.c_float), ("note", C.c_char * 192)]
 
 
 class SceneInfo(C.Structure):
@@ -49,6 +49,9 @@ _SZ = C.c_size_t
 _EXTRA = {
     "terra_amd_last_error": (C.c_char_p, []),
     "terra_amd_clear_error": (None, []),
+    "terra_amd_first_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "terra_amd_clear_first_error": (None, []),
+    "terra_amd_thread_staging_bytes": (C.c_size_t, []),
     "terra_amd_device_count": (C.c_int, []),
     "terra_amd_set_device": (C.c_int, [C.c_int]),
     "terra_amd_get_device": (C.c_int, []),
@@ -57,6 +60,8 @@ _EXTRA = {
     "terra_amd_set_tree_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_tree_mode": (C.c_int, [C.c_void_p]),
     "terra_amd_traversal_info": (C.c_int, [C.c_void_p, C.POINTER(TraversalInfo)]),
+    "terra_amd_set_tree_builder": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_get_tree_builder": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sample_split": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_sample_split": (C.c_int, [C.c_void_p]),
     "terra_amd_set_environment_lighting": (C.c_int, [C.c_void_p, C.c_int]),
@@ -102,6 +107,13 @@ def check(rc: int, what: str = "") -> int:
 
 def last_error() -> str:
     return load().last_error().decode()
+
+
+def first_error():
+    """(status, message) of the first error any thread recorded since the last clear_first_error(); (0, "") if none"""
+    buf = C.create_string_buffer(512)
+    st = load().first_error(buf, 512)
+    return st, buf.value.decode()
 
 
 class DeviceFramebuffer:

@@ -363,6 +363,46 @@ def test_automatic_mode_falls_back_per_call_when_the_camera_is_far(H, L):
     assert same(H, a["pixels"], b["pixels"]) and a["stats"]["nodes"] == b["stats"]["nodes"]       # the reference tree was traversed
 
 
+def test_fast_tree_built_on_the_device(H, L):
+    """terra_amd_set_tree_builder(1): LBVH built on the GPU from the soup in HBM -- another tree shape, the same image"""
+    import torch
+    from test_oracle_vs_reference import soup_scene
+    g = G(H, "render_hall")
+    cases = [scenes.sponza_hall(160, 90, 2, integrator=0), scenes.sponza_hall(64, 36, 1, integrator=1)]
+    soup = soup_scene(H, 3000, 44, integrator=2); soup.width, soup.height, soup.spp = 80, 48, 3
+    cases.append(soup)
+    dup = soup_scene(H, 400, 45, integrator=0); dup.width, dup.height, dup.spp = 64, 40, 2
+    for o in dup.objects:                                   # coincident triangles: equal Morton codes and equal depths (rank tie-breaks)
+        o.triangles = np.concatenate([o.triangles, o.triangles]); o.normals = np.concatenate([o.normals, o.normals]); o.texcoords = np.concatenate([o.texcoords, o.texcoords])
+    cases.append(dup)
+    for k, d in enumerate(cases):
+        outs = []
+        for builder in (0, 1):
+            L.clear_error()
+            scene = scenes.build_scene(L, d, tree_mode=1, tree_builder=builder)
+            assert runtime.last_error() == "", runtime.last_error()
+            ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(scene, C.byref(ti)))
+            assert ti.fast_tree == 1 and ti.fast_tree_built_on_device == builder
+            fb = runtime.DeviceFramebuffer(d.width, d.height); cam = scenes.camera_of(d)
+            rc = torch.zeros(d.width * d.height, dtype=torch.int32, device="cuda")
+            for _ in range(2):
+                runtime.render_device(L, cam, scene, fb, None, rc)
+            torch.cuda.synchronize()
+            st = runtime.Stats(); runtime.check(L.get_stats(scene, C.byref(st)))
+            outs.append((fb.pixels_host().copy(), fb.results_host()["acc"].copy(), rc.cpu().numpy().copy(), st.as_dict()))
+            L.scene_destroy(scene)
+        assert same(H, outs[0][0], outs[1][0]) and same(H, outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2]), k
+        assert outs[1][3]["nodes"] > 0 and outs[1][3]["rays"] == outs[0][3]["rays"] and outs[1][3]["hits"] == outs[0][3]["hits"]
+    # ... and it is the reference's image: the hall golden (one pass)
+    out = render_dev(L, scenes.sponza_hall(160, 90, 2, integrator=0), calls=True, tree_mode=1)
+    scene = scenes.build_scene(L, scenes.sponza_hall(160, 90, 2, integrator=0), tree_mode=2, tree_builder=1)       # automatic mode: built on the device, read back, containment-checked
+    ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(scene, C.byref(ti)))
+    assert ti.fast_tree_built_on_device == 1 and "device" in ti.note.decode()
+    fb = runtime.DeviceFramebuffer(160, 90); runtime.render_device(L, scenes.camera_of(scenes.sponza_hall(160, 90, 2)), scene, fb); torch.cuda.synchronize()
+    assert H.same_bits(fb.pixels_host(), g["i0_pixels"]) and H.same_bits(fb.pixels_host(), out["pixels"])
+    L.scene_destroy(scene)
+
+
 def test_fast_tree_hall_goldens_and_work(H, L):
     """the fast tree reproduces the REFERENCE's image of the 97k-triangle hall with a fraction of the traversal work"""
     g = G(H, "render_hall")

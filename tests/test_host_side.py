@@ -189,3 +189,20 @@ def test_automatic_traversal_decision(H, L):
     # fewer than 2 triangles: nothing to cull
     d = soup_scene(H, 1, 11, n_objects=1)
     assert _decision(L, d)[1:3] == (0, 0)
+
+
+def test_first_error_is_process_wide_and_sticky(H, L):
+    """a worker thread's failure is visible to the thread that polls; the first one is kept until cleared"""
+    import threading
+    L.clear_first_error(); L.clear_error()
+    assert runtime.first_error() == (0, "")
+    def worker():
+        L.set_tree_mode(L.scene_create(), 7)           # an error on another thread
+    t = threading.Thread(target=worker); t.start(); t.join()
+    assert runtime.last_error() == ""                   # this thread's channel is untouched ...
+    st, msg = runtime.first_error()
+    assert st < 0 and "tree mode 7" in msg              # ... the process-wide one has it
+    L.set_sample_split(L.scene_create(), 3)             # a later error does not replace the first
+    assert "sample split" in runtime.last_error() and "tree mode 7" in runtime.first_error()[1]
+    L.clear_first_error(); L.clear_error()
+    assert runtime.first_error() == (0, "")

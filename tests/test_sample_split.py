@@ -141,6 +141,19 @@ def test_threaded_tile_calls_with_automatic_split(H, L):
         fb.destroy(); L.scene_destroy(scene)
     assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32)) and np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))
     assert (frames[0][2] == 64).all()
+    # a worker stages its largest TILE, not the frame, and a worker's error reaches the polling thread through the process-wide channel
+    seen = {}
+    def probe():
+        scene = scenes.build_scene(L, d); fb = api.Framebuffer(L, d.width, d.height); cam = scenes.camera_of(d)
+        L.render(C.byref(cam), scene, C.byref(fb.fb), 64, 48, 64, 48)
+        seen["bytes"] = L.thread_staging_bytes()
+        L.render(C.byref(cam), scene, C.byref(fb.fb), 100, 100, 500, 500)          # outside the frame
+        fb.destroy(); L.scene_destroy(scene)
+    L.clear_first_error(); L.clear_error()
+    th = threading.Thread(target=probe); th.start(); th.join()
+    assert seen["bytes"] == 64 * 48 * 28
+    assert runtime.last_error() == "" and "bad tile rectangle" in runtime.first_error()[1]
+    L.clear_first_error()
     # a 64x48 tile is 12 blocks: the automatic rule gives 4 lanes per pixel at 64 spp (16 samples each) = 4 calls of 16
     want = dev(L, scenes.cornell_box(192, 128, 16, integrator=api.kTerraIntegratorDirect), passes=4)
     assert np.array_equal(frames[0][0].view(np.uint32), want["acc"].view(np.uint32))
