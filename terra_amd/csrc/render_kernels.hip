@@ -53,13 +53,14 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t
 #ifndef TERRA_CHECK_SHRINK
 #define TERRA_CHECK_SHRINK 0
 #endif
+template <int MODE>
 TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris, bool cull ) {
     const int tid = threadIdx.x;
     Tracer T;
     T.sc = sc;
     // [staged nodes][staged triangles][staged properties][stack][leaf list][parked words]  (sizes: terra_lds_bytes)
     float4* ln = lds;                                                // byte offset 0: a staged node's address is its stack word
-    float4* lt = ln + ( TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;
+    float4* lt = ln + ( MODE == 2 ? 4 : TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;      // MODE 2 stages a prefix of the fast tree as plain 64-B nodes
     float4* lp = lt + 3 * lds_tris;
     int* words = reinterpret_cast<int*> ( lp + 4 * lds_tris );
     T.stack = words + tid;
@@ -71,6 +72,10 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
     const float4* gt = reinterpret_cast<const float4*> ( sc.tris );
     const float4* gp = reinterpret_cast<const float4*> ( sc.props );
+    if ( MODE == 2 ) {        // hot nodes of the fast tree: its numbering is breadth first, so the first lds_nodes nodes are its top levels
+        const float4* fn = reinterpret_cast<const float4*> ( sc.fast_nodes );
+        for ( uint32_t i = tid; i < 4 * lds_nodes; i += TERRA_COL ) ln[i] = fn[i];
+    } else
     for ( uint32_t i = tid; i < lds_nodes; i += TERRA_COL ) {       // node i -> the axis-major, both-signs layout (trace_device.h "Staged node")
         const float4 q0 = gn[4 * i], q1 = gn[4 * i + 1], q2 = gn[4 * i + 2], q3 = gn[4 * i + 3];
         const float mn0[3] = { q0.x, q0.y, q0.z }, mx0[3] = { q0.w, q1.x, q1.y }, mn1[3] = { q1.z, q1.w, q2.x }, mx1[3] = { q2.y, q2.z, q2.w };
@@ -236,7 +241,7 @@ template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
-    Tracer T0 = make_tracer ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0 );
+    Tracer T0 = make_tracer<MODE> ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0 );
     T0.faults = p.counters + kCtrFaults;
     const Tracer T = T0;
 
@@ -469,8 +474,19 @@ static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank
     return tiles > rank ? ( tiles - rank + world - 1 ) / world : 0;
 }
 
-size_t terra_lds_bytes ( uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris ) {
-    return ( size_t ) ( stack_depth + leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) lds_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) lds_tris * ( 48 + 64 );
+size_t terra_lds_bytes ( const DevRenderParams& p ) {
+    return ( size_t ) ( p.stack_depth + p.leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) p.lds_nodes * ( p.lds_mode == 2 ? 64 : TERRA_LDS_NODE_BYTES ) + ( size_t ) p.lds_tris * ( 48 + 64 );
+}
+// fast tree (MODE 2): nodes of its breadth-first prefix staged per block. The kernel is latency bound (a ray's node fetches are a
+// dependent chain through L2 / Infinity Cache) and on the 97k-triangle hall the first 64 / 256 / 1024 nodes receive 39 / 57 / 70 % of
+// all node visits (profiles/r02_measurements/phase_hall_fast.log), so a small prefix shortens the chain more than the resident block
+// it may cost: A/B in profiles/r02_measurements/ab_prefix.log.
+#ifndef TERRA_FAST_PREFIX_NODES      // (tree_build.cpp numbers this many top-level nodes first)
+#define TERRA_FAST_PREFIX_NODES 64
+#endif
+void terra_plan_fast_tree ( DevRenderParams& p ) {
+    p.lds_mode = 2; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) ( p.scene.fast_max_stack < 1 ? 1 : p.scene.fast_max_stack );
+    p.lds_nodes = p.scene.n_fast_nodes < ( uint32_t ) TERRA_FAST_PREFIX_NODES ? p.scene.n_fast_nodes : ( uint32_t ) TERRA_FAST_PREFIX_NODES;
 }
 
 // LDS plan. Small scenes (whole scene + stack + a leaf list of at least TERRA_LEAF_CAP_RESIDENT_MIN entries <= budget): stage
@@ -545,7 +561,7 @@ hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) 
     uint32_t bpt = p.tile_size / 16;
     uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt * p.split;
     if ( blocks == 0 ) return hipSuccess;
-    size_t lds = terra_lds_bytes ( p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris );
+    size_t lds = terra_lds_bytes ( p );
     switch ( p.integrator ) {
         case 0: return launch_one<0> ( p, blocks, lds, stream );
         case 1: return launch_one<1> ( p, blocks, lds, stream );

@@ -853,7 +853,10 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     terra_plan_lds ( p );
     // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
     const bool cam_ok = coords_within_margin ( p.cam_pos, 3 );
-    if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) { p.lds_mode = 2; p.lds_nodes = 0; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) s->dev.fast_max_stack; }
+    if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) {
+        terra_plan_fast_tree ( p );
+        if ( s->fast_on_device ) p.lds_nodes = 0;      // the device-built tree is not numbered top-levels-first: nothing worth staging
+    }
     p.leaf_cull = ( s->cull_ok && cam_ok && p.lds_mode != 2 ) ? 1u : 0u;
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;

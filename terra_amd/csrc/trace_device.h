@@ -100,7 +100,8 @@ TD Counters counters_zero() {
 #define PS_WAVE(c, k) do { } while ( 0 )
 #define PS_LANE(c, k) do { } while ( 0 )
 #endif
-enum { kPsRayIter = 0, kPsNodeIter, kPsLeafIter, kPsShadeIter, kPsCamIter, kPsCamLanes, kPsRayLanes, kPsShadeLanes, kPsNodeLanes, kPsLeafLanes, kPsDrainIter };
+enum { kPsRayIter = 0, kPsNodeIter, kPsLeafIter, kPsShadeIter, kPsCamIter, kPsCamLanes, kPsRayLanes, kPsShadeLanes, kPsNodeLanes, kPsLeafLanes, kPsDrainIter,
+       kPsTop64, kPsTop256, kPsTop1024, kPsTop4096 };      // node visits that fall into the first K nodes of the (breadth-first numbered) array: what an LDS-staged prefix would serve
 
 // -----------------------------------------------------------------------------
 // camera
@@ -370,6 +371,9 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
         }
     } else {
         const float4* g_nodes = reinterpret_cast<const float4*> ( T.sc.nodes );
+#if TERRA_PHASE_STATS
+        c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
+#endif
         const float4 q0 = g_nodes[4 * w], q1 = g_nodes[4 * w + 1], q2 = g_nodes[4 * w + 2], q3 = g_nodes[4 * w + 3];
         child0 = __float_as_uint ( q3.x ); child1 = __float_as_uint ( q3.y );
         hit0 = slab<FAST> ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r );
@@ -474,9 +478,13 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
             top -= TERRA_COL;
             uint32_t w = ( uint32_t ) * top;
             if ( w & DEV_CHILD_LEAF ) { leaf = w; break; }
-            float4 q0 = nodes[4 * w], q1 = nodes[4 * w + 1], q2 = nodes[4 * w + 2], q3 = nodes[4 * w + 3];
+            const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout
+            float4 q0 = nsrc[4 * w], q1 = nsrc[4 * w + 1], q2 = nsrc[4 * w + 2], q3 = nsrc[4 * w + 3];
             uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
             if ( COUNT ) ++c.nodes;
+#if TERRA_PHASE_STATS
+            c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
+#endif
             float te0, te1;
             bool hit0 = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te0 ) && te0 <= best.depth && child0 != DEV_CHILD_EMPTY;
             bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;

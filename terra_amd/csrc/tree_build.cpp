@@ -116,6 +116,9 @@ void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nod
 // ---- fast tree: 3-axis binned SAH, BVH2, leaves of <= 4 triangles ----------
 // Built over the same per-triangle boxes as the reference (triangle bounds +- 1e-4) so every
 // triangle a ray can hit lies inside its ancestors' boxes; inner boxes are plain unions.
+#ifndef TERRA_FAST_PREFIX_NODES  // nodes of the fast tree's top levels numbered first (and staged in LDS by the MODE 2 kernel; render_kernels.hip)
+#define TERRA_FAST_PREFIX_NODES 64
+#endif
 #ifndef TERRA_FAST_LEAF_MAX      // triangles per leaf of the fast tree (the leaf word holds count-1 in 4 bits)
 #define TERRA_FAST_LEAF_MAX 4
 #endif
@@ -213,6 +216,25 @@ Built build ( std::vector<Prim>& prims ) {
             todo.push_back ( { m, t.hi, ( int ) idx, 1, t.depth + 1 } );
         }
         out.max_stack = max_depth + 2;     // ordered traversal: at most one extra pending entry per level
+    }
+    // Numbering: the first TERRA_FAST_PREFIX_NODES nodes in breadth-first order (the levels every ray visits: the kernel stages them
+    // in LDS), all others in the order they were created (a node is followed by one child's whole subtree: a descent finds its next
+    // nodes close by; measured on the 97k-triangle hall, a fully breadth-first array renders 3.7 % slower).
+    {
+        const size_t K = std::min ( out.nodes.size(), ( size_t ) TERRA_FAST_PREFIX_NODES );
+        std::vector<uint32_t> order, newidx ( out.nodes.size(), 0xffffffffu );
+        order.reserve ( out.nodes.size() ); order.push_back ( 0 ); newidx[0] = 0;
+        for ( size_t head = 0; head < order.size() && order.size() < K; ++head ) {
+            const DevNode& nd = out.nodes[order[head]];
+            for ( int k = 0; k < 2 && order.size() < K; ++k ) if ( nd.child[k] != DEV_CHILD_EMPTY && ! ( nd.child[k] & DEV_CHILD_LEAF ) ) { newidx[nd.child[k]] = ( uint32_t ) order.size(); order.push_back ( nd.child[k] ); }
+        }
+        for ( uint32_t i = 0; i < out.nodes.size(); ++i ) if ( newidx[i] == 0xffffffffu ) { newidx[i] = ( uint32_t ) order.size(); order.push_back ( i ); }
+        std::vector<DevNode> renum ( order.size() );
+        for ( size_t k = 0; k < order.size(); ++k ) {
+            renum[k] = out.nodes[order[k]];
+            for ( int c = 0; c < 2; ++c ) if ( renum[k].child[c] != DEV_CHILD_EMPTY && ! ( renum[k].child[c] & DEV_CHILD_LEAF ) ) renum[k].child[c] = newidx[renum[k].child[c]];
+        }
+        out.nodes.swap ( renum );
     }
     out.order.resize ( ( size_t ) n );
     for ( int i = 0; i < n; ++i ) out.order[ ( size_t ) i] = prims[ ( size_t ) i].soup;

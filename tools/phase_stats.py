@@ -16,7 +16,7 @@ import torch  # noqa: F401  first: the library binds to the HIP runtime torch lo
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from terra_amd import api, runtime, scenes  # noqa: E402
 
-NAMES = ["ray_iter", "node_iter", "leaf_iter", "shade_iter", "cam_iter", "cam_lanes", "ray_lanes", "shade_lanes", "node_lanes", "leaf_lanes", "drain_iter"]
+NAMES = ["ray_iter", "node_iter", "leaf_iter", "shade_iter", "cam_iter", "cam_lanes", "ray_lanes", "shade_lanes", "node_lanes", "leaf_lanes", "drain_iter", "top64", "top256", "top1024", "top4096"]
 
 
 def main():
@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--split", type=int, default=8)
     ap.add_argument("--integrator", type=int, default=0)
     ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--tree", type=int, default=None, help="terra_amd_set_tree_mode")
     a = ap.parse_args()
     L = runtime.load()
-    mk = {"cornell": scenes.cornell_box, "phong": scenes.cornell_phong}[a.scene]
+    mk = {"cornell": scenes.cornell_box, "phong": scenes.cornell_phong, "hall": scenes.sponza_hall}[a.scene]
     d = mk(1920, 1080, a.spp, bounces=8, integrator=a.integrator)
-    scene = scenes.build_scene(L, d)
+    scene = scenes.build_scene(L, d, tree_mode=a.tree)
     runtime.check(L.set_sample_split(scene, a.split))
     fb = runtime.DeviceFramebuffer(d.width, d.height); cam = scenes.camera_of(d)
     runtime.render_device(L, cam, scene, fb)
@@ -44,6 +45,8 @@ def main():
         if v[it]:
             print(f"{ph:6s} wave execs {v[it]:14d}  lanes {v[ln]:16d}  utilisation {v[ln] / (64.0 * v[it]):.3f}   per ray-iter {v[it] / max(1, v['ray_iter']):.2f}")
     print(f"drains per ray-iter {v['drain_iter'] / max(1, v['ray_iter']):.3f}")
+    if v["top4096"]:
+        print("node visits served by a breadth-first prefix of the node array: " + ", ".join(f"first {k}: {100.0 * v['top' + str(k)] / st['nodes']:.1f} %" for k in (64, 256, 1024, 4096)) + f"  ({st['nodes'] / st['rays']:.1f} nodes per ray)")
 
 
 if __name__ == "__main__":
