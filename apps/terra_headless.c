@@ -9,17 +9,29 @@
  * for PNG, raw floats for HDR). It links against libterra_amd.so or, unchanged, against the
  * reference's objects (only Terra.h / TerraPresets.h symbols are used; terra_amd_* are weak).
  *
- * Parity note: the reference imports OBJ with its Apollo importer (satellite/include/Apollo.h),
- * which does not compile with this image's toolchains, so THIS LOADER IS NOT PINNED to it
- * ("parity unpinned"). Known differences: vertex normals from the file are used when present
- * (Apollo always recomputes them); otherwise area-weighted smooth normals per position.
+ * Import policy (--normals apollo, the default): the reference's client imports OBJ with its Apollo importer
+ * (satellite/include/Apollo.h:964-1700) under the options of satellite/src/Scene.cpp:83-93 -- recompute_vertex_normals,
+ * remove_vertex_duplicates, flip_z, flip_faces_winding_order. Apollo.h does not compile with this image's toolchains, so its
+ * policy is RESTATED here and pinned by hand-derived fixtures (tests/test_headless_tool.py), not by running it:
+ *   - one object per `g` / `o` group (a group is opened implicitly by the first `usemtl`, `s` or `f`); the group's material is
+ *     the LAST `usemtl` inside it; `illum specular` (Apollo's own MTL dialect) or a non-zero Ks selects Phong;
+ *   - z is negated at parse time and every triangle (a, b, c) becomes (c, b, a);
+ *   - the file's `vn` are ignored. Face normal = normalize(cross(v1 - v0, v2 - v0)) of the flipped triangle. A group is smooth
+ *     iff its last `s` token starts with '1'; in smooth groups corners with bit-equal positions share one vertex (the first one
+ *     created anywhere in the file) and its first texcoord. A vertex normal is the normalised, unweighted sum of the face
+ *     normals of the triangles the vertex was PARSED for: corners 0-2 of a polygon count for its first triangle only, corner
+ *     j >= 3 for triangle j - 2 (Apollo records adjacency per parsed corner, Apollo.h:1373-1381); `s off` / `s 0` groups get
+ *     the face normal per triangle; groups without any `s` take the smooth path without sharing, i.e. face normals again.
+ * --normals file keeps the file's `vn` (area-weighted smooth normals per position where absent) and one object per material:
+ * this repo's own policy, not the reference's.
  *
  *   terra_headless scene.obj out.png [--width W] [--height H] [--spp N] [--bounces N]
  *       [--integrator simple|direct|mis|normals|depth] [--tonemap none|linear|reinhard|filmic|uncharted2]
  *       [--camera px py pz dx dy dz] [--fov deg] [--exposure e] [--gamma g] [--jitter j]
- *       [--no-flip-z] [--fast-tree | --auto-tree] [--sample-split n] [--seed n] [--tile n]
+ *       [--no-flip-z] [--normals apollo|file] [--dump-scene file] [--no-render] [--fast-tree | --replica-tree] [--sample-split n] [--seed n] [--tile n]
  */
 #include <ctype.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,13 +47,19 @@ void        terra_amd_set_frame_seed ( HTerraScene, uint64_t ) __attribute__ ( (
 #define VEC(T) struct { T* d; size_t n, cap; }
 #define PUSH(v, x) do { if ( ( v ).n == ( v ).cap ) { ( v ).cap = ( v ).cap ? ( v ).cap * 2 : 256; ( v ).d = realloc ( ( v ).d, ( v ).cap * sizeof *( v ).d ); } ( v ).d[( v ).n++] = ( x ); } while ( 0 )
 
-typedef struct { char name[128]; float kd[3], ks[3], ke[3], ns; } Mtl;
+typedef struct { char name[128]; float kd[3], ks[3], ke[3], ns; int illum_specular; } Mtl;     /* illum_specular: 1 / 0 from Apollo's `illum specular|diffuse`, -1 unset */
 typedef struct { int v[3], t[3], n[3]; int mtl; } Face;
+typedef struct { int v, t, n; } Corner;
+typedef struct { size_t first, count; int group; } Poly;              /* corners [first, first + count) in file order */
+typedef struct { int smooth, mtl; } Group;                            /* smooth: -1 no `s` seen, else 1 / 0 */
 
 typedef struct {
     VEC ( TerraFloat3 ) pos, nrm;
     VEC ( TerraFloat2 ) uv;
     VEC ( Face ) faces;
+    VEC ( Corner ) corners;
+    VEC ( Poly ) polys;
+    VEC ( Group ) groups;
     VEC ( Mtl ) mtls;
 } Model;
 
@@ -63,13 +81,14 @@ static void load_mtl ( Model* m, const char* dir, const char* file ) {
         if ( strcmp ( key, "newmtl" ) == 0 ) {
             Mtl x; memset ( &x, 0, sizeof x );
             sscanf ( rest, "%127s", x.name );
-            x.kd[0] = x.kd[1] = x.kd[2] = 0.7f; x.ns = 1.f;
+            x.kd[0] = x.kd[1] = x.kd[2] = 0.7f; x.ns = 1.f; x.illum_specular = -1;
             PUSH ( m->mtls, x ); cur = &m->mtls.d[m->mtls.n - 1];
         } else if ( cur ) {
             if ( strcmp ( key, "Kd" ) == 0 ) sscanf ( rest, "%f %f %f", &cur->kd[0], &cur->kd[1], &cur->kd[2] );
             else if ( strcmp ( key, "Ks" ) == 0 ) sscanf ( rest, "%f %f %f", &cur->ks[0], &cur->ks[1], &cur->ks[2] );
             else if ( strcmp ( key, "Ke" ) == 0 ) sscanf ( rest, "%f %f %f", &cur->ke[0], &cur->ke[1], &cur->ke[2] );
             else if ( strcmp ( key, "Ns" ) == 0 ) sscanf ( rest, "%f", &cur->ns );
+            else if ( strcmp ( key, "illum" ) == 0 ) { char v[64] = ""; sscanf ( rest, "%63s", v ); if ( !strcmp ( v, "specular" ) ) cur->illum_specular = 1; else if ( !strcmp ( v, "diffuse" ) ) cur->illum_specular = 0; }
         }
     }
     fclose ( f );
@@ -84,6 +103,7 @@ static int load_obj ( Model* m, const char* path ) {
     const char* slash = strrchr ( path, '/' );
     if ( slash ) { size_t k = ( size_t ) ( slash - path ) + 1; if ( k < sizeof dir ) { memcpy ( dir, path, k ); dir[k] = 0; } }
     char line[4096]; int cur_mtl = -1;
+#define NEED_GROUP() do { if ( m->groups.n == 0 ) { Group g0 = { -1, -1 }; PUSH ( m->groups, g0 ); } } while ( 0 )
     while ( fgets ( line, sizeof line, f ) ) {
         char* p = line;
         while ( isspace ( ( unsigned char ) *p ) ) ++p;
@@ -102,11 +122,20 @@ static int load_obj ( Model* m, const char* path ) {
                 vi[cnt] = fix_index ( a, m->pos.n ); ti[cnt] = fix_index ( b, m->uv.n ); ni[cnt] = fix_index ( c, m->nrm.n ); ++cnt;
                 tok = strtok ( NULL, " \t\r\n" );
             }
+            if ( cnt >= 3 ) {
+                NEED_GROUP();
+                Poly pl = { m->corners.n, ( size_t ) cnt, ( int ) m->groups.n - 1 };
+                int ok = 1;
+                for ( int k = 0; k < cnt; ++k ) if ( vi[k] < 0 ) ok = 0;
+                if ( ok ) { for ( int k = 0; k < cnt; ++k ) { Corner c = { vi[k], ti[k], ni[k] }; PUSH ( m->corners, c ); } PUSH ( m->polys, pl ); }
+            }
             for ( int k = 1; k + 1 < cnt; ++k ) {       /* fan triangulation */
                 Face fc = { { vi[0], vi[k], vi[k + 1] }, { ti[0], ti[k], ti[k + 1] }, { ni[0], ni[k], ni[k + 1] }, cur_mtl };
                 if ( fc.v[0] >= 0 && fc.v[1] >= 0 && fc.v[2] >= 0 ) PUSH ( m->faces, fc );
             }
-        } else if ( strncmp ( p, "usemtl", 6 ) == 0 ) { char name[128] = ""; sscanf ( p + 6, "%127s", name ); cur_mtl = find_mtl ( m, name ); }
+        } else if ( strncmp ( p, "usemtl", 6 ) == 0 ) { char name[128] = ""; sscanf ( p + 6, "%127s", name ); cur_mtl = find_mtl ( m, name ); NEED_GROUP(); m->groups.d[m->groups.n - 1].mtl = cur_mtl; }
+        else if ( ( p[0] == 'g' || p[0] == 'o' ) && p[1] == ' ' ) { Group g = { -1, -1 }; PUSH ( m->groups, g ); }       /* Apollo.h:1205-1218: groups and objects alike open a mesh */
+        else if ( p[0] == 's' && p[1] == ' ' ) { NEED_GROUP(); m->groups.d[m->groups.n - 1].smooth = p[2] == '1' ? 1 : 0; }           /* Apollo.h:1225-1240: smooth iff the character after "s " is '1' */
         else if ( strncmp ( p, "mtllib", 6 ) == 0 ) { char name[512] = ""; sscanf ( p + 6, "%511s", name ); load_mtl ( m, dir, name ); }
     }
     fclose ( f );
@@ -116,7 +145,10 @@ static int load_obj ( Model* m, const char* path ) {
 /* ---- scene construction ---------------------------------------------------------------------- */
 static TerraFloat3 flipz ( TerraFloat3 v, int flip ) { if ( flip ) v.z = -v.z; return v; }
 
-static HTerraScene build_scene ( Model* m, int flip ) {
+static void set_material ( TerraObject* o, const Mtl* mt );
+static void dump_object ( FILE* f, size_t j, const TerraObject* o );
+
+static HTerraScene build_scene ( Model* m, int flip, FILE* dump ) {
     /* smooth normals per position for faces without vn */
     TerraFloat3* smooth = calloc ( m->pos.n ? m->pos.n : 1, sizeof ( TerraFloat3 ) );
     for ( size_t i = 0; i < m->faces.n; ++i ) {
@@ -154,27 +186,143 @@ static HTerraScene build_scene ( Model* m, int flip ) {
             o->properties[k].texcoord_a = T[0]; o->properties[k].texcoord_b = T[1]; o->properties[k].texcoord_c = T[2];
             ++k;
         }
-        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f;
-        const Mtl* mt = want >= 0 ? &m->mtls.d[want] : &def;
-        TerraFloat3 kd = terra_f3_setv ( mt->kd ), ks = terra_f3_setv ( mt->ks ), ke = terra_f3_setv ( mt->ke ), zero = terra_f3_zero;
-        o->material.ior = 1.5f;                                /* Scene.cpp:187 */
-        terra_attribute_init_constant ( &o->material.emissive, &ke );
-        if ( ks.x + ks.y + ks.z > 0.f ) {                      /* specular -> Phong (Scene.cpp:193-213) */
-            TerraFloat3 ns = terra_f3_set1 ( mt->ns );
-            terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_ALBEDO], &kd );
-            terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_SPECULAR_COLOR], &ks );
-            terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_SPECULAR_INTENSITY], &ns );
-            terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_SAMPLE_PICK], &zero );
-            o->material.attributes_count = TERRA_PHONG_END;
-            terra_bsdf_phong_init ( &o->material.bsdf );
-        } else {                                               /* everything else -> diffuse (Scene.cpp:215-230) */
-            terra_attribute_init_constant ( &o->material.attributes[TERRA_DIFFUSE_ALBEDO], &kd );
-            o->material.attributes_count = TERRA_DIFFUSE_END;
-            terra_bsdf_diffuse_init ( &o->material.bsdf );
-        }
+        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f; def.illum_specular = -1;
+        set_material ( o, want >= 0 ? &m->mtls.d[want] : &def );
+        if ( dump ) dump_object ( dump, terra_scene_count_objects ( scene ) - 1, o );
     }
     free ( smooth );
     return scene;
+}
+
+/* ---- the reference importer's policy (see the header comment) ------------------------------------ */
+typedef struct { TerraFloat3 pos; TerraFloat2 tex; TerraFloat3 norm; VEC ( unsigned ) adj; } AVert;
+typedef struct { unsigned bits[3]; unsigned value; int used; } VSlot;
+static unsigned pos_hash ( const unsigned* b ) { unsigned h = 2166136261u; for ( int i = 0; i < 3; ++i ) { h ^= b[i]; h *= 16777619u; h ^= h >> 13; } return h; }
+
+static void set_material ( TerraObject* o, const Mtl* mt ) {
+    TerraFloat3 kd = terra_f3_setv ( mt->kd ), ks = terra_f3_setv ( mt->ks ), ke = terra_f3_setv ( mt->ke ), zero = terra_f3_zero;
+    o->material.ior = 1.5f;                                /* Scene.cpp:187 */
+    terra_attribute_init_constant ( &o->material.emissive, &ke );
+    const int phong = mt->illum_specular >= 0 ? mt->illum_specular : ( ks.x + ks.y + ks.z > 0.f );
+    if ( phong ) {                                         /* specular -> Phong (Scene.cpp:193-213) */
+        TerraFloat3 ns = terra_f3_set1 ( mt->ns );
+        terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_ALBEDO], &kd );
+        terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_SPECULAR_COLOR], &ks );
+        terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_SPECULAR_INTENSITY], &ns );
+        terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_SAMPLE_PICK], &zero );
+        o->material.attributes_count = TERRA_PHONG_END;
+        terra_bsdf_phong_init ( &o->material.bsdf );
+    } else {                                               /* everything else -> diffuse (Scene.cpp:215-230) */
+        terra_attribute_init_constant ( &o->material.attributes[TERRA_DIFFUSE_ALBEDO], &kd );
+        o->material.attributes_count = TERRA_DIFFUSE_END;
+        terra_bsdf_diffuse_init ( &o->material.bsdf );
+    }
+}
+
+static HTerraScene build_scene_apollo ( Model* m, int flip, FILE* dump ) {
+    VEC ( AVert ) verts; memset ( &verts, 0, sizeof verts );
+    VEC ( unsigned ) idx; memset ( &idx, 0, sizeof idx );
+    VEC ( int ) tri_group; memset ( &tri_group, 0, sizeof tri_group );
+    size_t cap = 64; while ( cap < 4 * ( m->corners.n + 1 ) ) cap *= 2;
+    VSlot* table = calloc ( cap, sizeof ( VSlot ) );
+    int zero_used = 0; unsigned zero_value = 0;
+    unsigned face_count = 0;
+    for ( size_t pi = 0; pi < m->polys.n; ++pi ) {
+        const Poly* pl = &m->polys.d[pi];
+        const int smooth = m->groups.d[pl->group].smooth;
+        unsigned first = 0, last = 0;
+        for ( size_t j = 0; j < pl->count; ++j ) {
+            const Corner* c = &m->corners.d[pl->first + j];
+            TerraFloat3 pos = flipz ( m->pos.d[c->v], flip );                     /* z is negated when the `v` line is read (Apollo.h:1167) */
+            unsigned bits[3]; memcpy ( bits, &pos, 12 );
+            for ( int k = 0; k < 3; ++k ) if ( bits[k] == 0x80000000u ) bits[k] = 0;      /* float equality: -0 == +0 */
+            const int is_zero = !bits[0] && !bits[1] && !bits[2];
+            unsigned index = 0; int dup = 0;
+            size_t slot = pos_hash ( bits ) & ( cap - 1 );
+            if ( smooth == 1 ) {                                                  /* lookup only inside smooth groups (Apollo.h:1349-1356) */
+                if ( is_zero ) { if ( zero_used ) { index = zero_value; dup = 1; } }
+                else for ( size_t s2 = slot; table[s2].used; s2 = ( s2 + 1 ) & ( cap - 1 ) ) if ( !memcmp ( table[s2].bits, bits, 12 ) ) { index = table[s2].value; dup = 1; break; }      /* the first one inserted */
+            }
+            if ( !dup ) {
+                AVert v; memset ( &v, 0, sizeof v );
+                v.pos = pos; v.tex = c->t >= 0 ? m->uv.d[c->t] : terra_f2_set ( 0.f, 0.f );
+                PUSH ( verts, v ); index = ( unsigned ) verts.n - 1;
+                if ( is_zero ) { zero_used = 1; zero_value = index; }              /* the all-zero key keeps the LAST vertex (Apollo.h:2180-2184) */
+                else { size_t s2 = slot; while ( table[s2].used ) s2 = ( s2 + 1 ) & ( cap - 1 ); memcpy ( table[s2].bits, bits, 12 ); table[s2].value = index; table[s2].used = 1; }
+            }
+            {   /* adjacency: the triangle being formed while this corner is parsed (Apollo.h:1373-1381) */
+                AVert* v = &verts.d[index]; int seen = 0;
+                for ( size_t a = 0; a < v->adj.n; ++a ) if ( v->adj.d[a] == face_count ) seen = 1;
+                if ( !seen ) PUSH ( v->adj, face_count );
+            }
+            if ( j == 0 ) first = index;
+            if ( j >= 3 ) { PUSH ( idx, first ); PUSH ( idx, last ); }             /* fan: (first, previous, current) */
+            PUSH ( idx, index );
+            if ( j >= 2 ) { last = index; PUSH ( tri_group, pl->group ); ++face_count; }
+        }
+    }
+    if ( flip ) for ( size_t i = 0; i + 2 < idx.n; i += 3 ) { unsigned t = idx.d[i]; idx.d[i] = idx.d[i + 2]; idx.d[i + 2] = t; }      /* Apollo.h:1412-1418 */
+    TerraFloat3* fn = malloc ( ( face_count ? face_count : 1 ) * sizeof ( TerraFloat3 ) );
+    for ( unsigned i = 0; i < face_count; ++i ) {                                  /* Apollo.h:1438-1462 */
+        TerraFloat3 v0 = verts.d[idx.d[3 * i]].pos, v1 = verts.d[idx.d[3 * i + 1]].pos, v2 = verts.d[idx.d[3 * i + 2]].pos;
+        TerraFloat3 e01 = { v1.x - v0.x, v1.y - v0.y, v1.z - v0.z }, e02 = { v2.x - v0.x, v2.y - v0.y, v2.z - v0.z };
+        TerraFloat3 n = { e01.y * e02.z - e01.z * e02.y, e01.z * e02.x - e01.x * e02.z, e01.x * e02.y - e01.y * e02.x };
+        float len = sqrtf ( n.x * n.x + n.y * n.y + n.z * n.z );
+        n.x /= len; n.y /= len; n.z /= len;
+        fn[i] = n;
+    }
+    unsigned char* done = calloc ( verts.n ? verts.n : 1, 1 );
+    for ( size_t g = 0; g < m->groups.n; ++g ) {                                   /* Apollo.h:1465-1541, group after group */
+        memset ( done, 0, verts.n );
+        for ( unsigned i = 0; i < face_count; ++i ) {
+            if ( tri_group.d[i] != ( int ) g ) continue;
+            for ( int k = 0; k < 3; ++k ) {
+                AVert* v = &verts.d[idx.d[3 * i + k]];
+                if ( m->groups.d[g].smooth == 0 ) { v->norm = fn[i]; continue; }
+                if ( done[idx.d[3 * i + k]] ) continue;
+                done[idx.d[3 * i + k]] = 1;
+                TerraFloat3 sum = { 0.f, 0.f, 0.f };
+                for ( size_t a = 0; a < v->adj.n; ++a ) { sum.x += fn[v->adj.d[a]].x; sum.y += fn[v->adj.d[a]].y; sum.z += fn[v->adj.d[a]].z; }
+                float len = sqrtf ( sum.x * sum.x + sum.y * sum.y + sum.z * sum.z );
+                sum.x /= len; sum.y /= len; sum.z /= len;
+                v->norm = sum;
+            }
+        }
+    }
+    HTerraScene scene = terra_scene_create();
+    for ( size_t g = 0; g < m->groups.n; ++g ) {
+        size_t cnt = 0;
+        for ( unsigned i = 0; i < face_count; ++i ) if ( tri_group.d[i] == ( int ) g ) ++cnt;
+        if ( !cnt ) continue;
+        TerraObject* o = terra_scene_add_object ( scene, cnt );
+        size_t k = 0;
+        for ( unsigned i = 0; i < face_count; ++i ) {
+            if ( tri_group.d[i] != ( int ) g ) continue;
+            const AVert* a = &verts.d[idx.d[3 * i]]; const AVert* b = &verts.d[idx.d[3 * i + 1]]; const AVert* c = &verts.d[idx.d[3 * i + 2]];
+            o->triangles[k].a = a->pos; o->triangles[k].b = b->pos; o->triangles[k].c = c->pos;
+            o->properties[k].normal_a = a->norm; o->properties[k].normal_b = b->norm; o->properties[k].normal_c = c->norm;
+            o->properties[k].texcoord_a = a->tex; o->properties[k].texcoord_b = b->tex; o->properties[k].texcoord_c = c->tex;
+            ++k;
+        }
+        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f; def.illum_specular = -1;
+        set_material ( o, m->groups.d[g].mtl >= 0 ? &m->mtls.d[m->groups.d[g].mtl] : &def );
+        if ( dump ) dump_object ( dump, terra_scene_count_objects ( scene ) - 1, o );
+    }
+    for ( size_t i = 0; i < verts.n; ++i ) free ( verts.d[i].adj.d );
+    free ( verts.d ); free ( idx.d ); free ( tri_group.d ); free ( table ); free ( fn ); free ( done );
+    return scene;
+}
+
+/* --dump-scene: every object exactly as it was filled through terra_scene_add_object (text, %.9g round-trips a float): for the loader's tests */
+static void dump_object ( FILE* f, size_t j, const TerraObject* o ) {
+    fprintf ( f, "object %zu triangles %zu attributes %zu\n", j, o->triangles_count, o->material.attributes_count );
+    for ( size_t i = 0; i < o->triangles_count; ++i ) {
+        const TerraTriangle* t = &o->triangles[i]; const TerraTriangleProperties* q = &o->properties[i];
+        fprintf ( f, "t %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g n %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g uv %.9g %.9g %.9g %.9g %.9g %.9g\n",
+                  t->a.x, t->a.y, t->a.z, t->b.x, t->b.y, t->b.z, t->c.x, t->c.y, t->c.z,
+                  q->normal_a.x, q->normal_a.y, q->normal_a.z, q->normal_b.x, q->normal_b.y, q->normal_b.z, q->normal_c.x, q->normal_c.y, q->normal_c.z,
+                  q->texcoord_a.x, q->texcoord_a.y, q->texcoord_b.x, q->texcoord_b.y, q->texcoord_c.x, q->texcoord_c.y );
+    }
 }
 
 /* ---- image writers --------------------------------------------------------------------------- */
@@ -259,7 +407,8 @@ static int pick ( const char* v, const char* const* names, int n, int dflt ) { f
 int main ( int argc, char** argv ) {
     if ( argc < 3 ) { fprintf ( stderr, "usage: terra_headless scene.obj out.{png,ppm,pfm,hdr} [options]\n" ); return 64; }
     size_t W = 800, H = 600, spp = 8, bounces = 4, tile = 0;     /* defaults of satellite/include/Config.hpp:19-113 */
-    int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = 0, have_seed = 0, split = -1;
+    int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = -1, have_seed = 0, split = -1, apollo = 1;
+    const char* dump_path = NULL; int no_render = 0;
     float fov = 45.f, exposure = 1.f, gamma = 2.2f, jitter = 0.f;
     unsigned long long seed = 0;
     TerraCamera cam; cam.position = terra_f3_set ( 0.f, 1.f, -3.4f ); cam.direction = terra_f3_set ( 0.f, 0.f, 1.f ); cam.up = terra_f3_set ( 0.f, 1.f, 0.f );
@@ -279,6 +428,10 @@ int main ( int argc, char** argv ) {
         else if ( !strcmp ( a, "--no-flip-z" ) ) flip = 0;
         else if ( !strcmp ( a, "--fast-tree" ) ) fast = 1;
         else if ( !strcmp ( a, "--auto-tree" ) ) fast = 2;
+        else if ( !strcmp ( a, "--replica-tree" ) ) fast = 0;
+        else if ( !strcmp ( a, "--normals" ) ) { const char* v = NEXT(); if ( !strcmp ( v, "apollo" ) ) apollo = 1; else if ( !strcmp ( v, "file" ) ) apollo = 0; else { fprintf ( stderr, "terra_headless: --normals apollo|file\n" ); return 64; } }
+        else if ( !strcmp ( a, "--dump-scene" ) ) dump_path = NEXT();
+        else if ( !strcmp ( a, "--no-render" ) ) no_render = 1;
         else if ( !strcmp ( a, "--sample-split" ) ) split = atoi ( NEXT() );
         else if ( !strcmp ( a, "--integrator" ) ) { static const char* const n[] = { "simple", "direct", "mis", "mono", "depth", "normals", "misweights" }; integrator = pick ( NEXT(), n, 7, integrator ); }
         else if ( !strcmp ( a, "--tonemap" ) ) { static const char* const n[] = { "none", "linear", "reinhard", "filmic", "uncharted2" }; tonemap = pick ( NEXT(), n, 5, tonemap ); }
@@ -290,14 +443,18 @@ int main ( int argc, char** argv ) {
     cam.fov = fov;
     Model m; memset ( &m, 0, sizeof m );
     if ( !load_obj ( &m, argv[1] ) ) { fprintf ( stderr, "terra_headless: no faces in %s\n", argv[1] ); return 66; }
-    HTerraScene scene = build_scene ( &m, flip );
+    FILE* dump = dump_path ? fopen ( dump_path, "w" ) : NULL;
+    if ( dump_path && !dump ) { fprintf ( stderr, "terra_headless: cannot write %s\n", dump_path ); return 73; }
+    HTerraScene scene = apollo ? build_scene_apollo ( &m, flip, dump ) : build_scene ( &m, flip, dump );
+    if ( dump ) fclose ( dump );
+    if ( no_render ) { printf ( "%s: %zu objects\n", argv[1], terra_scene_count_objects ( scene ) ); terra_scene_destroy ( scene ); return 0; }
     TerraSceneOptions* o = terra_scene_get_options ( scene );
     TerraFloat3 env = terra_f3_set ( 0.4f, 0.52f, 1.f );
     terra_attribute_init_constant ( &o->environment_map, &env );
     o->tonemapping_operator = ( TerraTonemappingOperator ) tonemap; o->accelerator = kTerraAcceleratorBVH; o->sampling_method = kTerraSamplingMethodRandom;
     o->integrator = ( TerraIntegrator ) integrator; o->subpixel_jitter = jitter; o->samples_per_pixel = spp; o->bounces = bounces; o->strata = 4;
     o->manual_exposure = exposure; o->gamma = gamma;
-    if ( fast && terra_amd_set_tree_mode ) terra_amd_set_tree_mode ( scene, fast );
+    if ( fast >= 0 && terra_amd_set_tree_mode ) terra_amd_set_tree_mode ( scene, fast );
     if ( split >= 0 && terra_amd_set_sample_split ) terra_amd_set_sample_split ( scene, split );
     if ( have_seed && terra_amd_set_frame_seed ) terra_amd_set_frame_seed ( scene, seed );
     terra_scene_commit ( scene );

@@ -8,7 +8,7 @@ from terra_amd import api, runtime, scenes
 lib = runtime.load(); f = lib.fn("terra_amd_debug_faults", C.c_longlong, [C.c_void_p])
 print("library", lib.path.split('/')[-1])
 for name, d in (("hall", scenes.sponza_hall(320, 180, 4)), ("spheres", scenes.cornell_spheres(320, 180, 8)), ("cornell", scenes.cornell_box(320, 180, 16))):
-    for tm in (0, 1):
+    for tm in (0, 1, 2):
         for integ in (0, 1, 2):
             d.integrator = integ
             s = scenes.build_scene(lib, d, tree_mode=tm); fb = runtime.DeviceFramebuffer(d.width, d.height)
@@ -22,7 +22,7 @@ sys.path.insert(0,'.')
 from terra_amd import api, runtime, scenes
 lib = runtime.load(); f = lib.fn("terra_amd_debug_faults", C.c_longlong, [C.c_void_p])
 d = scenes.sponza_hall(160, 90, 2)
-for tm in (0, 1):
+for tm in (0, 1, 2):
     s = scenes.build_scene(lib, d, tree_mode=tm); fb = runtime.DeviceFramebuffer(d.width, d.height)
     runtime.render_device(lib, scenes.camera_of(d), s, fb); torch.cuda.synchronize()
     print("positive control (stack shrunk by 19): tree", tm, "faults", f(s)); lib.scene_destroy(s)
