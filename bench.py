@@ -473,15 +473,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d)
         headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == 8
         if world == 1 and not c.dist_on and headline and not args.no_workloads:
-            extra = []
+            extra = []; cpu_cache = {}
             for name, tree, integ, split, steps, warmup, prewarm, cpu_s in EXTRA_WORKLOADS:
                 dw = workload(name)
                 mw = measure(c, dw, tree, split, steps, warmup, prewarm_rect=prewarm)
                 b = result_block(dw, name, tree, split, steps, warmup, 1, mw, 0, integ)
                 if name.startswith("spheres"):
                     b["parity"] = "unpinned: the GGX and glass presets are this repo's definitions (the reference's are dead code, src/TerraPresets.c:298-465)"
-                if cpu_s and not args.no_cpu_baseline:
-                    b["cpu_baseline"] = cpu_baseline(dw, cpu_s)
+                if not args.no_cpu_baseline:          # the CPU renders the scene, not the tree mode: one measurement per workload
+                    if name not in cpu_cache and cpu_s:
+                        cpu_cache[name] = cpu_baseline(dw, cpu_s)
+                    if name in cpu_cache:
+                        b["cpu_baseline"] = cpu_cache[name]
                 extra.append(b)
             out["workloads"] = extra
         print(json.dumps(out), flush=True)
