@@ -258,21 +258,29 @@ def roofline(key, st, kernel_ms, lds_resident, world):
         out["pmc_stale"] = rec.get("source_digest") != source_digest()
         out["pmc_kernel_ms"] = rec.get("kernel_ms")
     traffic = rec.get("hbm_bytes_per_launch")
-    if lds_resident:
-        insts = rec.get("SQ_INSTS_VALU")
-        ach = insts / t / 1e9 if insts else None
-        out.update({"bound": "valu", "achieved": round(ach, 1) if ach else None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
-                    "frac": round(ach / VALU_PEAK_GINST, 4) if ach else None, "traffic": traffic,
-                    "lane_util": rec.get("lane_util"), "lds_bank_conflict_frac": rec.get("lds_bank_conflict_frac"), "valu_insts_per_launch": insts,
-                    "note": "scene staged in LDS: the kernel is bound by VALU issue; achieved = SQ_INSTS_VALU (profiles/r02_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
-                            "A stream of nothing but v_add_f32 sustains 0.96 G/s per SIMD on this part and VOP3 / f64 / integer-multiply streams 0.57 (profiles/r02_measurements/valu_rates.log), so frac ~0.6 is the practical ceiling of this instruction mix; "
-                            "`traffic` is what HBM moved (framebuffer only)"})
+    insts = rec.get("SQ_INSTS_VALU")
+    valu = insts / t / 1e9 if insts else None                      # G wave64 VALU instructions per second, whole chip
+    fabric = traffic / t / 1e9 if traffic else None                # GB/s the L2 moved on its fabric side
+    valu_frac = round(valu / VALU_PEAK_GINST, 4) if valu else None
+    fabric_frac = round(fabric / HBM_PEAK_GBS, 4) if fabric else None
+    out.update({"traffic": traffic, "valu_insts_per_launch": insts, "lane_util": rec.get("lane_util"), "lds_bank_conflict_frac": rec.get("lds_bank_conflict_frac"),
+                "valu_frac": valu_frac, "l2_fabric_frac": fabric_frac})
+    # the bound reported is the resource the kernel comes closest to saturating
+    if valu_frac is not None and (fabric_frac is None or valu_frac >= fabric_frac):
+        out.update({"bound": "valu", "achieved": round(valu, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": valu_frac})
+    elif fabric_frac is not None:
+        out.update({"bound": "l2_fabric", "achieved": round(fabric, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fabric_frac})
     else:
-        ach = traffic / t / 1e9 if traffic else None
-        out.update({"bound": "l2_fabric", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": traffic, "lane_util": rec.get("lane_util"),
-                    "note": "scene read from global memory (11 MB: L2 / Infinity Cache resident): achieved = bytes the L2 moved on its fabric side per launch (FETCH_SIZE x 2 + WRITE_SIZE PMC passes, "
-                            "Infinity Cache hits included; profiles/r02_pmc.json) / kernel time measured in this run, against the 8 TB/s HBM peak; the kernel is latency bound (dependent 64-B node fetches), not bandwidth bound"})
+        out.update({"bound": "valu" if lds_resident else "l2_fabric", "achieved": None, "peak": VALU_PEAK_GINST if lds_resident else HBM_PEAK_GBS,
+                    "unit": "G wave-instr/s" if lds_resident else "GB/s", "frac": None})
+    if lds_resident:
+        out["note"] = ("scene staged in LDS: the kernel is bound by VALU issue. achieved = SQ_INSTS_VALU (profiles/r02_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
+                       "A stream of nothing but v_add_f32 sustains 0.96 G/s per SIMD on this part and min/max/cmp/cndmask/f64/integer-multiply streams 0.57 (profiles/r02_measurements/valu_rates.log), so frac ~0.7 is "
+                       "saturation for this instruction mix; lane_util says how many of the issued lanes did work; `traffic` is what HBM moved (framebuffer only)")
+    else:
+        out["note"] = ("scene read from global memory (L2 / Infinity Cache resident): the kernel is latency bound -- a ray's node fetches are a dependent chain -- and saturates neither resource; valu_frac = SQ_INSTS_VALU / "
+                       "kernel time against the 1,229 G/s issue peak, l2_fabric_frac = bytes the L2 moved on its fabric side (FETCH_SIZE x 2 + WRITE_SIZE PMC passes, Infinity Cache hits included) / kernel time against the "
+                       "8 TB/s HBM peak; `bound` names the larger of the two")
     return out
 
 
