@@ -156,7 +156,13 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
                                 // profiles/r01_measurements/ab_dec_lds.log): there shading outweighs traversal, so it stays off
 #define TERRA_DECOUPLED_LDS 0
 #endif
-#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
+#ifndef TERRA_DECOUPLED_FAST     // ... and the fast-tree kernels (MODE 2)
+#define TERRA_DECOUPLED_FAST 1
+#endif
+#ifndef TERRA_FAST_EXIT_16THS    // MODE 2 leaves the traversal when this many 16ths of the lanes that entered it have finished (a ray is cheap there, so shading wants fuller waves)
+#define TERRA_FAST_EXIT_16THS 12
+#endif
+#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) || ( TERRA_DECOUPLED_FAST && ( M ) == 2 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
 // ... and Direct, whose one shadow ray per hit becomes a traversal job of its own (scenes without textured attributes)
 #ifndef TERRA_DECOUPLED_DIRECT_ENABLE
 #define TERRA_DECOUPLED_DIRECT_ENABLE 1
@@ -190,9 +196,9 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
-struct LaneTraversal { RayState st; SlabSel sel; Closest best; int top; bool traversing, regular; };     // top: entries on the lane's stack (its leaf list is always empty between calls)
+struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, leaf; int top; bool traversing, regular; };     // top: entries on the lane's stack (its leaf list is always empty between calls)
 TD LaneTraversal lane_traversal_idle ( const Tracer& T, const Ray& any_ray ) {
-    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.top = 0; t.traversing = false; t.regular = true;
+    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.leaf = 0; t.top = 0; t.traversing = false; t.regular = true;
     return t;
 }
 // puts `ray` in flight: the origin offset terra_scene_raycast applies (src/Terra.c:1629-1630), ray state, empty closest hit, root on the stack
@@ -202,7 +208,7 @@ TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t
     t.st = ray_state_init ( r );
     t.sel = slab_sel ( r );
     t.regular = ray_is_regular ( r );
-    t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu;
+    t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.leaf = 0;
     *T.stack = 0; t.top = 1;
     t.traversing = true;
     if ( COUNT ) ++c.rays;
@@ -212,13 +218,19 @@ template <int COUNT, int MODE>
 TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
     const int n_trav = __popcll ( __ballot ( t.traversing ) );
     if ( n_trav == 0 ) return false;
-    int quota = n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+    int quota = MODE == 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
     const int exit_active = n_trav - quota;
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
     int* sp = T.stack + t.top * TERRA_COL;
-    if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
-    else traverse_resume<COUNT, MODE, false> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
+    if constexpr ( MODE == 2 ) {
+        ClosestRanked b2; b2.depth = t.best.depth; b2.rank = t.rank; b2.tri = t.best.tri;
+        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.leaf, t.traversing, exit_active, c );
+        t.best.depth = b2.depth; t.best.tri = b2.tri; t.rank = b2.rank;
+    } else {
+        if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
+        else traverse_resume<COUNT, MODE, false> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
+    }
     t.top = ( int ) ( sp - T.stack ) / TERRA_COL;
     return true;
 }

@@ -448,57 +448,92 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 // (DevTri::pad of the fast soup). The triangle test itself is the same arithmetic.
 // Child word of a fast node: bit 31 leaf; leaf = (count-1) << 27 | first triangle.
 // -----------------------------------------------------------------------------
-TD bool slab_enter ( V3 bmin, V3 bmax, const Ray& r, float& t_enter ) {
-    float t1x = ( bmin.x - r.o.x ) * r.inv.x, t2x = ( bmax.x - r.o.x ) * r.inv.x;
-    float t1y = ( bmin.y - r.o.y ) * r.inv.y, t2y = ( bmax.y - r.o.y ) * r.inv.y;
-    float t1z = ( bmin.z - r.o.z ) * r.inv.z, t2z = ( bmax.z - r.o.z ) * r.inv.z;
-    float tmin = sel_min ( t1x, t2x ), tmax = sel_max ( t1x, t2x );
-    tmin = sel_max ( tmin, sel_min ( t1y, t2y ) ); tmax = sel_min ( tmax, sel_max ( t1y, t2y ) );
-    tmin = sel_max ( tmin, sel_min ( t1z, t2z ) ); tmax = sel_min ( tmax, sel_max ( t1z, t2z ) );
-    t_enter = sel_max ( tmin, 0.f );
+// Entry distance of a fast-tree box, stored as (centre, half extent) (tree_build_device.hip "Traversal form"). Unlike the
+// reference tree's test this one only has to be CONSERVATIVE (never reject a box that holds a triangle the ray hits; DESIGN.md
+// "Traversal policy"): near / far per axis come out of one subtraction and one addition, v_max3 / v_min3 drop a NaN (0 x inf or
+// inf - inf: a ray parallel to a box plane), which only widens the interval.
+#ifndef TERRA_FAST_CENTER_EXTENT
+#define TERRA_FAST_CENTER_EXTENT 1
+#endif
+TD bool slab_enter ( V3 c, V3 h, const Ray& r, float& t_enter ) {
+    if ( !TERRA_FAST_CENTER_EXTENT ) {          // (min, max) boxes: A/B builds only
+        float t1x = ( c.x - r.o.x ) * r.inv.x, t2x = ( h.x - r.o.x ) * r.inv.x;
+        float t1y = ( c.y - r.o.y ) * r.inv.y, t2y = ( h.y - r.o.y ) * r.inv.y;
+        float t1z = ( c.z - r.o.z ) * r.inv.z, t2z = ( h.z - r.o.z ) * r.inv.z;
+        float tmin = __builtin_fmaxf ( __builtin_fmaxf ( __builtin_fminf ( t1x, t2x ), __builtin_fminf ( t1y, t2y ) ), __builtin_fminf ( t1z, t2z ) );
+        float tmax = __builtin_fminf ( __builtin_fminf ( __builtin_fmaxf ( t1x, t2x ), __builtin_fmaxf ( t1y, t2y ) ), __builtin_fmaxf ( t1z, t2z ) );
+        t_enter = __builtin_fmaxf ( tmin, 0.f );
+        return tmax > t_enter;
+    }
+    const float tcx = ( c.x - r.o.x ) * r.inv.x, hx = h.x * __builtin_fabsf ( r.inv.x );
+    const float tcy = ( c.y - r.o.y ) * r.inv.y, hy = h.y * __builtin_fabsf ( r.inv.y );
+    const float tcz = ( c.z - r.o.z ) * r.inv.z, hz = h.z * __builtin_fabsf ( r.inv.z );
+    const float tmin = __builtin_fmaxf ( __builtin_fmaxf ( tcx - hx, tcy - hy ), tcz - hz );
+    const float tmax = __builtin_fminf ( __builtin_fminf ( tcx + hx, tcy + hy ), tcz + hz );
+    t_enter = __builtin_fmaxf ( tmin, 0.f );
     return tmax > t_enter;
 }
 
 struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
 
-// "while-while" form: leaves are pushed on the stack like inner nodes (near child last, so it is popped first);
-// a lane descends until it pops a leaf, then all lanes that hold one test its triangles together. Lanes no
-// longer wait, node after node, for neighbours that happen to be inside a leaf's triangle loop.
+// Leaves are pushed on the stack like inner nodes (near child last, so it is popped first). A lane that pops a leaf
+// HOLDS it; each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and
+// some lane can still descend) the descending lanes take a node step, otherwise the holders test one triangle each.
+// (16/16 is the classic "while-while" loop: descend until every lane holds a leaf.) The vote trades a fuller node step --
+// 6 x more executions than triangle steps on the hall -- against an emptier triangle step.
+// The traversal is resumable (stack column in LDS; top, held leaf, closest hit in registers): it returns as soon as the
+// number of lanes still traversing has dropped to `exit_active`, so the render loop can shade the finished lanes and hand
+// them their next ray (exit_active = 0: run every lane's ray to the end). `traversing` is cleared for lanes whose traversal
+// completed. What a lane computes, and in which order, does not depend on the votes.
+#ifndef TERRA_FAST_LEAF_16THS
+#define TERRA_FAST_LEAF_16THS 8
+#endif
 template <int COUNT>
-TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
+TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c ) {
+    // a ray parallel to an axis has an infinite inverse direction there, and inf - inf would drop that axis from the test:
+    // correct but ruinous (such a ray then visits every box along its line; one lane walking 20k nodes alone costs tens of
+    // milliseconds). Clamped to +-2^100 the axis keeps its meaning: (|c - o| - h) * 2^100 has the sign of "outside the slab".
+    Ray r = ray;
+    r.inv.x = __builtin_fminf ( __builtin_fmaxf ( r.inv.x, -0x1p100f ), 0x1p100f );
+    r.inv.y = __builtin_fminf ( __builtin_fmaxf ( r.inv.y, -0x1p100f ), 0x1p100f );
+    r.inv.z = __builtin_fminf ( __builtin_fmaxf ( r.inv.z, -0x1p100f ), 0x1p100f );
     const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
-    ClosestRanked best; best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
-    V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-    int* top = T.stack;
-    *top = 0; top += TERRA_COL;
     for ( ;; ) {
-        uint32_t leaf = 0;
-        while ( top != T.stack ) {
-            top -= TERRA_COL;
-            uint32_t w = ( uint32_t ) * top;
-            if ( w & DEV_CHILD_LEAF ) { leaf = w; break; }
-            const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout
-            float4 q0 = nsrc[4 * w], q1 = nsrc[4 * w + 1], q2 = nsrc[4 * w + 2], q3 = nsrc[4 * w + 3];
-            uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
-            if ( COUNT ) ++c.nodes;
+        const bool holder = traversing && leaf != 0;
+        const bool can = traversing && leaf == 0 && top != T.stack;
+        const int n_can = __popcll ( __ballot ( can ) ), n_hold = __popcll ( __ballot ( holder ) );
+        traversing = can || holder;                                  // a lane with an empty stack and no leaf in hand is done
+        if ( n_can + n_hold <= exit_active ) break;
+        if ( n_can != 0 && n_hold * 16 < ( n_can + n_hold ) * TERRA_FAST_LEAF_16THS ) {
+            if ( can ) {
+                PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
+                top -= TERRA_COL;
+                const uint32_t w = ( uint32_t ) * top;
+                if ( w & DEV_CHILD_LEAF ) leaf = w;
+                else {
+                    const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout
+                    float4 q0 = nsrc[4 * w], q1 = nsrc[4 * w + 1], q2 = nsrc[4 * w + 2], q3 = nsrc[4 * w + 3];
+                    uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+                    if ( COUNT ) ++c.nodes;
 #if TERRA_PHASE_STATS
-            c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
+                    c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
-            float te0, te1;
-            bool hit0 = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te0 ) && te0 <= best.depth && child0 != DEV_CHILD_EMPTY;
-            bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;
-            if ( hit0 && hit1 ) {
-                bool zero_near = te0 <= te1;
-                TERRA_PUSH ( T, top, ( zero_near ? child1 : child0 ) );
-                TERRA_PUSH ( T, top, ( zero_near ? child0 : child1 ) );
-            } else if ( hit0 ) { TERRA_PUSH ( T, top, child0 ); }
-            else if ( hit1 ) { TERRA_PUSH ( T, top, child1 ); }
-        }
-        if ( !leaf ) break;
-        const uint32_t first = leaf & 0x07ffffffu, cnt = ( ( leaf >> 27 ) & 0xfu ) + 1;
-        for ( uint32_t j = 0; j < cnt; ++j ) {
-            uint32_t ti = first + j;
+                    float te0, te1;
+                    bool hit0 = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te0 ) && te0 <= best.depth && child0 != DEV_CHILD_EMPTY;
+                    bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;
+                    if ( hit0 && hit1 ) {
+                        bool zero_near = te0 <= te1;
+                        TERRA_PUSH ( T, top, ( zero_near ? child1 : child0 ) );
+                        TERRA_PUSH ( T, top, ( zero_near ? child0 : child1 ) );
+                    } else if ( hit0 ) { TERRA_PUSH ( T, top, child0 ); }
+                    else if ( hit1 ) { TERRA_PUSH ( T, top, child1 ); }
+                }
+            }
+        } else if ( holder ) {
+            PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
+            const uint32_t ti = leaf & 0x07ffffffu;
+            leaf = ( leaf & 0x78000000u ) ? leaf + 1u - 0x08000000u : 0u;        // next triangle of the leaf, one fewer to go; 0 = nothing in hand
             float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
             V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
             float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
@@ -512,6 +547,16 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
             }
         }
     }
+}
+
+template <int COUNT>
+TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
+    ClosestRanked best; best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
+    V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+    int* top = T.stack;
+    *top = 0; top += TERRA_COL;
+    bool traversing = true; uint32_t leaf = 0;
+    traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, leaf, traversing, 0, c );
     return best;
 }
 

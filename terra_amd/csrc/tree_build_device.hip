@@ -215,3 +215,33 @@ hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* ra
     *max_stack_out = ( int ) depth + 2;             // ordered traversal: at most one extra pending entry per level (as fastbvh::build)
     return hipSuccess;
 }
+
+// -----------------------------------------------------------------------------
+// Traversal form of a fast-tree node: each child box (min, max) becomes (centre, half extent), same 24 bytes, so that the
+// slab test needs no per-axis min / max:  t_near = (c - o) * inv - h * |inv|,  t_far = (c - o) * inv + h * |inv|  -- five
+// full-rate instructions per axis instead of four plus two half-rate ones (profiles/r02_measurements/valu_rates.log).
+// The new box CONTAINS the old one (h is rounded up from a double-precision difference), which is all the fast tree's
+// traversal needs (DESIGN.md "Traversal policy"); the commit-time containment check runs on the (min, max) boxes before this.
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__ ( 256 ) void tb_center_extent_kernel ( DevNode* nodes, uint32_t n ) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if ( i >= 2 * n ) return;
+    DevNode& nd = nodes[i >> 1];
+    float* mn = ( i & 1 ) ? nd.min1 : nd.min0; float* mx = ( i & 1 ) ? nd.max1 : nd.max0;
+    #pragma unroll
+    for ( int a = 0; a < 3; ++a ) {
+        const float lo = mn[a], hi = mx[a];
+        const float c = 0.5f * ( lo + hi );
+        const double hd = fmax ( ( double ) c - ( double ) lo, ( double ) hi - ( double ) c );
+        float h = ( float ) hd;
+        if ( ( double ) h < hd ) h = __uint_as_float ( __float_as_uint ( h ) + 1u );      // round up (h >= 0 here)
+        if ( !( lo <= hi ) ) h = -1.f;                                                      // an empty box stays empty
+        mn[a] = c; mx[a] = h;
+    }
+}
+hipError_t terra_fast_nodes_center_extent ( DevNode* nodes, uint32_t n, hipStream_t stream ) {
+    if ( n == 0 ) return hipSuccess;
+    hipLaunchKernelGGL ( tb_center_extent_kernel, dim3 ( ( 2 * n + 255 ) / 256 ), dim3 ( 256 ), 0, stream, nodes, n );
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? e : hipStreamSynchronize ( stream );
+}

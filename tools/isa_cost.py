@@ -18,7 +18,7 @@ start = next(i for i, l in enumerate(txt) if re.match(r"^_Z19terra_render_kernel
 blocks = []; cur = ["entry", []]; blocks.append(cur)
 for l in txt[start + 1:]:
     if "s_endpgm" in l: break
-    m = re.match(r"^(\.LBB\d+_\d+):", l)
+    m = re.match(r"^(\.LBB\d+_\d+):", l) or re.match(r"^; (%bb\.\d+):", l)      # fall-through blocks carry only a comment label
     if m: cur = [m.group(1), []]; blocks.append(cur); continue
     t = l.strip()
     if not t or t.startswith(";") or t.startswith("."): continue
