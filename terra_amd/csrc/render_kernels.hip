@@ -167,11 +167,17 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_DIRECT_ENABLE
 #define TERRA_DECOUPLED_DIRECT_ENABLE 1
 #endif
-#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( M ) == 0 && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#ifndef TERRA_DECOUPLED_FAST_DIRECT  // ... also on the fast tree (MODE 2): hall, 32 spp, 112.0 -> 108.2 ms
+#define TERRA_DECOUPLED_FAST_DIRECT 1
+#endif
+#ifndef TERRA_DECOUPLED_FAST_MIS     // Direct + MIS on the fast tree is faster coupled (hall, 32 spp: 168.6 ms against 187.7 decoupled; profiles/r02_measurements/ab_fast_light.log)
+#define TERRA_DECOUPLED_FAST_MIS 0
+#endif
+#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) == 2 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_DECOUPLED_MIS_ENABLE
 #define TERRA_DECOUPLED_MIS_ENABLE 1
 #endif
-#define TERRA_DECOUPLED_MIS(I, M, K) ( TERRA_DECOUPLED_MIS_ENABLE && ( M ) == 0 && ( I ) == 2 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#define TERRA_DECOUPLED_MIS(I, M, K) ( TERRA_DECOUPLED_MIS_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_MIS && ( M ) == 2 ) ) && ( I ) == 2 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_WAVES_DECOUPLED
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
@@ -235,6 +241,13 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
     return true;
 }
 
+// the closest hit as the index the light tables use (the soup): the fast tree's triangles are in leaf order and carry (object, triangle in object)
+template <int MODE>
+TD uint32_t hit_soup_index ( const Tracer& T, uint32_t tri ) {
+    if ( MODE != 2 || tri == 0xffffffffu ) return tri;
+    const float4* ft = reinterpret_cast<const float4*> ( T.sc.fast_tris );
+    return T.sc.mats[__float_as_uint ( ft[3 * tri].w )].first_tri + __float_as_uint ( ft[3 * tri + 1].w );
+}
 // a returned path segment's hit: the surface the reference's terra_scene_raycast hands to terra_trace (src/Terra.c:1640-1655)
 template <int COUNT, int MODE, int KINDS>
 TD V3 shade_surface ( const Tracer& T, const Ray& ray, const Closest& best, Surface& sf, Counters& c ) {
@@ -290,19 +303,19 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 if ( have_ray && job != 0 ) {
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
                     const bool hit = lt.best.tri != 0xffffffffu;
-                    Surface lsf; uint32_t object = 0, tri_in_object = 0, nattr = 0;
+                    Surface lsf; uint32_t object = 0, tri_in_object = 0, nattr = 0, tri_s = 0xffffffffu;
                     V3 point = hit ? r.o + r.d * lt.best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
                     if ( hit ) {
-                        if ( job == 2 ) surface_init<MODE, KINDS> ( T, lt.best.tri, point, lsf, object, tri_in_object, nattr );
-                        else { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * lt.best.tri]; object = __float_as_uint ( t0.w ); nattr = T.sc.mats[object].attributes_count; }
+                        if ( job == 2 ) { surface_init<MODE, KINDS> ( T, lt.best.tri, point, lsf, object, tri_in_object, nattr ); tri_s = MODE == 2 ? T.sc.mats[object].first_tri + tri_in_object : lt.best.tri; }
+                        else { tri_s = hit_soup_index<MODE> ( T, lt.best.tri ); const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * tri_s]; object = __float_as_uint ( t0.w ); nattr = T.sc.mats[object].attributes_count; }
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
                     }
                     if ( job == 1 ) {                            // A came back: pick its outcome, send B
-                        lo_i = lt.best.tri == pend.expected ? pend.a_vis : pend.a_hid;
+                        lo_i = tri_s == pend.expected ? pend.a_vis : pend.a_hid;
                         ray = make_ray ( b_o, b_d ); job = 2; start = true;
                     } else {                                     // B came back: the integrator's value is complete
-                        Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, lt.best.tri, point, lsf, ray.d );
+                        Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, tri_s, point, lsf, ray.d );
                         job = 0;
                         if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
                         else { deposit ( acc_lds, Lo ); have_ray = false; }
@@ -349,11 +362,12 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
             if ( !lt.traversing && !done ) {
                 bool start = false;
                 if ( have_ray && shadow ) {                      // the shadow ray came back
-                    if ( lt.best.tri != 0xffffffffu ) {             // (its hit counts as a surface init, as in the coupled form)
+                    const uint32_t tri_s = hit_soup_index<MODE> ( T, lt.best.tri );
+                    if ( tri_s != 0xffffffffu ) {                   // (its hit counts as a surface init, as in the coupled form)
                         if ( COUNT ) ++c.hits;
-                        if ( COUNT == 2 ) { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * lt.best.tri]; c.attr_fetches += T.sc.mats[__float_as_uint ( t0.w )].attributes_count + 1; }
+                        if ( COUNT == 2 ) { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * tri_s]; c.attr_fetches += T.sc.mats[__float_as_uint ( t0.w )].attributes_count + 1; }
                     }
-                    Lo = Lo + ( lt.best.tri == pend.expected ? pend.vis : pend.hid );
+                    Lo = Lo + ( tri_s == pend.expected ? pend.vis : pend.hid );
                     shadow = false;
                     if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
                     else { deposit ( acc_lds, Lo ); have_ray = false; }

@@ -499,17 +499,21 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
     r.inv.z = __builtin_fminf ( __builtin_fmaxf ( r.inv.z, -0x1p100f ), 0x1p100f );
     const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
+    // `cur`: the node a lane descends into next stays in a register (the near child when both are hit); only the far child
+    // goes through the stack, so a descent step does not wait for an LDS write + read of its own
+    uint32_t cur = DEV_CHILD_EMPTY;
     for ( ;; ) {
         const bool holder = traversing && leaf != 0;
-        const bool can = traversing && leaf == 0 && top != T.stack;
+        const bool can = traversing && leaf == 0 && ( cur != DEV_CHILD_EMPTY || top != T.stack );
         const int n_can = __popcll ( __ballot ( can ) ), n_hold = __popcll ( __ballot ( holder ) );
-        traversing = can || holder;                                  // a lane with an empty stack and no leaf in hand is done
+        traversing = can || holder;                                  // a lane with nothing in hand and an empty stack is done
         if ( n_can + n_hold <= exit_active ) break;
         if ( n_can != 0 && n_hold * 16 < ( n_can + n_hold ) * TERRA_FAST_LEAF_16THS ) {
             if ( can ) {
                 PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
-                top -= TERRA_COL;
-                const uint32_t w = ( uint32_t ) * top;
+                uint32_t w = cur;
+                if ( w == DEV_CHILD_EMPTY ) { top -= TERRA_COL; w = ( uint32_t ) * top; }
+                cur = DEV_CHILD_EMPTY;
                 if ( w & DEV_CHILD_LEAF ) leaf = w;
                 else {
                     const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout
@@ -525,9 +529,9 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
                     if ( hit0 && hit1 ) {
                         bool zero_near = te0 <= te1;
                         TERRA_PUSH ( T, top, ( zero_near ? child1 : child0 ) );
-                        TERRA_PUSH ( T, top, ( zero_near ? child0 : child1 ) );
-                    } else if ( hit0 ) { TERRA_PUSH ( T, top, child0 ); }
-                    else if ( hit1 ) { TERRA_PUSH ( T, top, child1 ); }
+                        cur = zero_near ? child0 : child1;
+                    } else if ( hit0 ) cur = child0;
+                    else if ( hit1 ) cur = child1;
                 }
             }
         } else if ( holder ) {
@@ -547,6 +551,7 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             }
         }
     }
+    if ( cur != DEV_CHILD_EMPTY ) { TERRA_PUSH ( T, top, cur ); }      // leaving with a node in hand: it waits on the stack
 }
 
 template <int COUNT>
