@@ -621,6 +621,7 @@ static int upload_scene ( Scene* s ) {
             double t_phase = now_s();
             fastbvh::Built built = fastbvh::build ( prims );        // (reorders prims into leaf order)
             phase ( "fast tree (host)", t_phase );
+            if ( timing_on() ) fprintf ( stderr, "[terra_amd timing]   fast tree: %zu nodes, stack %d entries\n", built.nodes.size(), built.max_stack );
             std::string why;
             std::vector<TerraAABB> leaf_boxes ( prims.size() );
             for ( size_t k = 0; k < prims.size(); ++k ) leaf_boxes[k] = prims[k].box;

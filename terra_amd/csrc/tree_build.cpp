@@ -122,6 +122,9 @@ void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nod
 #ifndef TERRA_FAST_LEAF_MAX      // triangles per leaf of the fast tree (the leaf word holds count-1 in 4 bits)
 #define TERRA_FAST_LEAF_MAX 4
 #endif
+#ifndef TERRA_FAST_SAH_TRI_COST
+#define TERRA_FAST_SAH_TRI_COST 3.0f
+#endif
 namespace fastbvh {
 
 static inline void grow ( TerraAABB& b, const TerraAABB& o ) {
@@ -156,9 +159,34 @@ Built build ( std::vector<Prim>& prims ) {
     std::vector<Task> todo;
     int max_depth = 1;
     auto bounds = [&] ( int lo, int hi ) { TerraAABB b = empty(); for ( int i = lo; i < hi; ++i ) grow ( b, prims[i].box ); return b; };
-    auto split = [&] ( int lo, int hi, int& mid ) -> bool {
+    auto split = [&] ( int lo, int hi, int& mid, bool refine ) -> bool {
         const int cnt = hi - lo;
-        if ( cnt <= TERRA_FAST_LEAF_MAX ) return false;
+        if ( cnt <= 1 ) return false;
+        if ( cnt <= TERRA_FAST_LEAF_MAX ) {
+            if ( !refine ) return false;
+            // a range that may become a leaf: exact sweep over the three axes, split only if the surface-area estimate says the extra
+            // node step is cheaper than the triangle steps it saves. TERRA_FAST_SAH_TRI_COST = cost of a triangle step in node steps as the
+            // kernel runs them (350 vs 160 issue cycles, at 0.3 vs 0.46 lane utilisation on the hall: profiles/r02_measurements/ab_fast_tree_loop.log)
+            const float pa = half_area ( bounds ( lo, hi ) );
+            float best = ( float ) cnt * TERRA_FAST_SAH_TRI_COST; int best_axis = -1, best_k = 0;
+            for ( int a = 0; a < 3 && pa > 0.f; ++a ) {
+                int idx[TERRA_FAST_LEAF_MAX];
+                for ( int i = 0; i < cnt; ++i ) idx[i] = lo + i;
+                std::sort ( idx, idx + cnt, [&] ( int x, int y ) { return prims[x].c[a] < prims[y].c[a] || ( prims[x].c[a] == prims[y].c[a] && prims[x].soup < prims[y].soup ); } );
+                for ( int k = 1; k < cnt; ++k ) {
+                    TerraAABB l = empty(), r = empty();
+                    for ( int i = 0; i < k; ++i ) grow ( l, prims[idx[i]].box );
+                    for ( int i = k; i < cnt; ++i ) grow ( r, prims[idx[i]].box );
+                    const float cost = 1.f + ( half_area ( l ) * ( float ) k + half_area ( r ) * ( float ) ( cnt - k ) ) / pa * TERRA_FAST_SAH_TRI_COST;
+                    if ( cost < best ) { best = cost; best_axis = a; best_k = k; }
+                }
+            }
+            if ( best_axis < 0 ) return false;
+            const int a = best_axis;
+            std::sort ( prims.begin() + lo, prims.begin() + hi, [&] ( const Prim & x, const Prim & y ) { return x.c[a] < y.c[a] || ( x.c[a] == y.c[a] && x.soup < y.soup ); } );
+            mid = lo + best_k;
+            return true;
+        }
         float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
         for ( int i = lo; i < hi; ++i ) for ( int a = 0; a < 3; ++a ) { cmin[a] = std::min ( cmin[a], prims[i].c[a] ); cmax[a] = std::max ( cmax[a], prims[i].c[a] ); }
         const int B = 16;
@@ -195,30 +223,45 @@ Built build ( std::vector<Prim>& prims ) {
     };
     if ( n == 0 ) { out.nodes[0].child[0] = DEV_CHILD_EMPTY; out.nodes[0].child[1] = DEV_CHILD_EMPTY; out.max_stack = 1; return out; }
     int mid = 0;
-    if ( !split ( 0, n, mid ) ) {
+    if ( !split ( 0, n, mid, false ) ) {
         set_child ( out.nodes[0], 0, bounds ( 0, n ), make_leaf ( 0, n ) );
         out.nodes[0].child[1] = DEV_CHILD_EMPTY;
         out.max_stack = 1;
     } else {
+        // pass 1: ranges of more than TERRA_FAST_LEAF_MAX triangles are split, smaller ones become leaves; pass 2 splits those leaves
+        // further where the surface-area estimate pays -- but never below the depth pass 1 reached, because the traversal stack
+        // (one KB of LDS per entry and block) is sized by the depth and the kernel's occupancy hangs on it
+        std::vector<Task> leaves;
+        auto run = [&] ( bool refine, int depth_cap ) {
+            while ( !todo.empty() ) {
+                Task t = todo.back(); todo.pop_back();
+                max_depth = std::max ( max_depth, t.depth );
+                TerraAABB b = bounds ( t.lo, t.hi );
+                int m = 0;
+                if ( ( refine && t.depth >= depth_cap ) || !split ( t.lo, t.hi, m, refine ) ) {
+                    set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, make_leaf ( t.lo, t.hi ) );
+                    if ( !refine && t.hi - t.lo > 1 ) leaves.push_back ( t );
+                    continue;
+                }
+                uint32_t idx = ( uint32_t ) out.nodes.size();
+                out.nodes.push_back ( DevNode() );
+                memset ( &out.nodes.back(), 0, sizeof ( DevNode ) );
+                set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, idx );
+                todo.push_back ( { t.lo, m, ( int ) idx, 0, t.depth + 1 } );
+                todo.push_back ( { m, t.hi, ( int ) idx, 1, t.depth + 1 } );
+            }
+        };
         todo.push_back ( { 0, mid, 0, 0, 1 } );
         todo.push_back ( { mid, n, 0, 1, 1 } );
-        while ( !todo.empty() ) {
-            Task t = todo.back(); todo.pop_back();
-            max_depth = std::max ( max_depth, t.depth );
-            TerraAABB b = bounds ( t.lo, t.hi );
-            int m = 0;
-            if ( !split ( t.lo, t.hi, m ) ) { set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, make_leaf ( t.lo, t.hi ) ); continue; }
-            uint32_t idx = ( uint32_t ) out.nodes.size();
-            out.nodes.push_back ( DevNode() );
-            memset ( &out.nodes.back(), 0, sizeof ( DevNode ) );
-            set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, idx );
-            todo.push_back ( { t.lo, m, ( int ) idx, 0, t.depth + 1 } );
-            todo.push_back ( { m, t.hi, ( int ) idx, 1, t.depth + 1 } );
-        }
-        out.max_stack = max_depth + 2;     // ordered traversal: at most one extra pending entry per level
+        run ( false, 0 );
+        const int depth_cap = max_depth;
+        todo.swap ( leaves );
+        run ( true, depth_cap );
+        // ordered traversal with the near child kept in a register: one pending (far) child per level, plus the node in hand when a lane leaves the loop
+        out.max_stack = max_depth + 1;
     }
     // Numbering: the first TERRA_FAST_PREFIX_NODES nodes in breadth-first order (the levels every ray visits: the kernel stages them
-    // in LDS), all others in the order they were created (a node is followed by one child's whole subtree: a descent finds its next
+    // in LDS), all others depth first (a node is followed by one child's whole subtree: a descent finds its next
     // nodes close by; measured on the 97k-triangle hall, a fully breadth-first array renders 3.7 % slower).
     {
         const size_t K = std::min ( out.nodes.size(), ( size_t ) TERRA_FAST_PREFIX_NODES );
@@ -228,7 +271,15 @@ Built build ( std::vector<Prim>& prims ) {
             const DevNode& nd = out.nodes[order[head]];
             for ( int k = 0; k < 2 && order.size() < K; ++k ) if ( nd.child[k] != DEV_CHILD_EMPTY && ! ( nd.child[k] & DEV_CHILD_LEAF ) ) { newidx[nd.child[k]] = ( uint32_t ) order.size(); order.push_back ( nd.child[k] ); }
         }
-        for ( uint32_t i = 0; i < out.nodes.size(); ++i ) if ( newidx[i] == 0xffffffffu ) { newidx[i] = ( uint32_t ) order.size(); order.push_back ( i ); }
+        {   // the rest depth first (a node is followed by one child's whole subtree), whichever pass created it
+            std::vector<uint32_t> st; st.push_back ( 0 );
+            while ( !st.empty() ) {
+                const uint32_t i = st.back(); st.pop_back();
+                if ( newidx[i] == 0xffffffffu ) { newidx[i] = ( uint32_t ) order.size(); order.push_back ( i ); }
+                const DevNode& nd = out.nodes[i];
+                for ( int k = 0; k < 2; ++k ) if ( nd.child[k] != DEV_CHILD_EMPTY && ! ( nd.child[k] & DEV_CHILD_LEAF ) ) st.push_back ( nd.child[k] );
+            }
+        }
         std::vector<DevNode> renum ( order.size() );
         for ( size_t k = 0; k < order.size(); ++k ) {
             renum[k] = out.nodes[order[k]];

@@ -212,7 +212,7 @@ hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* ra
     TB_TRY ( hipMemcpyAsync ( &depth, misc + 6, 4, hipMemcpyDeviceToHost, stream ) );
     TB_TRY ( hipStreamSynchronize ( stream ) );
     *n_nodes_out = tail[0];
-    *max_stack_out = ( int ) depth + 2;             // ordered traversal: at most one extra pending entry per level (as fastbvh::build)
+    *max_stack_out = ( int ) depth + 1;             // one pending (far) child per level + the node in hand when a lane leaves the loop (as fastbvh::build)
     return hipSuccess;
 }
 
