@@ -182,7 +182,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
 #ifndef TERRA_WAVES_FAST_TREE      // fast-tree (MODE 2) kernels are latency bound: more resident waves pay for the extra scratch
-#define TERRA_WAVES_FAST_TREE 6     // (hall, 32 spp: 4 -> 81.2 ms, 5 -> 71.0 ms, 6 -> 67.2 ms; profiles/r01_measurements/ab_fw.log)
+#define TERRA_WAVES_FAST_TREE 5     // (round 1, coupled loop: 4 -> 81.2 ms, 5 -> 71.0, 6 -> 67.2; with the decoupled loop, hall 64 spp: 5 -> 82.0 ms, 6 -> 83.6, 7 -> 89.0)
 #endif
 #ifndef TERRA_WAVES_FAST_TREE_LIGHT  // (hall, 16 spp, Direct / MIS: 4 -> 85.0 / 135.3 ms, 5 -> 79.3 / 122.2 ms, 6 -> 74.7 / 114.5 ms; ab_fl*.log)
 #define TERRA_WAVES_FAST_TREE_LIGHT 6
