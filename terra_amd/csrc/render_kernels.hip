@@ -173,7 +173,14 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_FAST_MIS     // Direct + MIS on the fast tree is faster coupled (hall, 32 spp: 168.6 ms against 187.7 decoupled; profiles/r02_measurements/ab_fast_light.log)
 #define TERRA_DECOUPLED_FAST_MIS 0
 #endif
-#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) == 2 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#ifndef TERRA_DECOUPLED_LDS_DIRECT   // ... and on LDS-resident scenes (MODE 1): measured SLOWER (Cornell Direct 128 spp: 43.3 ms coupled, 54.9 decoupled waiting for all lanes,
+                                     // 55.2 at 12/16, 50.1 with 5 waves/SIMD; profiles/r02_measurements/ab_fast_light.log), so it stays off
+#define TERRA_DECOUPLED_LDS_DIRECT 0
+#endif
+#ifndef TERRA_LDS_EXIT_16THS
+#define TERRA_LDS_EXIT_16THS 16
+#endif
+#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) == 2 ) || ( TERRA_DECOUPLED_LDS_DIRECT && ( M ) == 1 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_DECOUPLED_MIS_ENABLE
 #define TERRA_DECOUPLED_MIS_ENABLE 1
 #endif
@@ -224,7 +231,7 @@ template <int COUNT, int MODE>
 TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
     const int n_trav = __popcll ( __ballot ( t.traversing ) );
     if ( n_trav == 0 ) return false;
-    int quota = MODE == 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+    int quota = MODE == 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : MODE == 1 ? ( n_trav * TERRA_LDS_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
     const int exit_active = n_trav - quota;
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
