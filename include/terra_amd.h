@@ -211,6 +211,10 @@ int terra_amd_unit_watertight ( int n, const float* origins3, const float* dirs3
 int terra_amd_unit_moller_trumbore ( int n, const float* origins3, const float* dirs3, const float* tris9, int* hit, float* out4 );
 /* terra_bvh_traverse on the committed scene (src/TerraBVH.c:250-310): prim = obj | tri<<8, point3 */
 int terra_amd_unit_bvh_traverse ( HTerraScene scene, int n, const float* origins3, const float* dirs3, int* found, uint32_t* prim, float* point3 );
+/* The same query through the fast tree (terra_amd_set_tree_mode 1 / 2; ordered, culled traversal, ties resolved by the
+   reference's leaf visit order): same found / prim / point3 as terra_amd_unit_bvh_traverse for any ray, plus the number of
+   nodes each ray visited. Fails if the committed scene has no fast tree. */
+int terra_amd_unit_bvh_traverse_fast ( HTerraScene scene, int n, const float* origins3, const float* dirs3, int* found, uint32_t* prim, float* point3, uint32_t* nodes_visited );
 /* terra_scene_raycast + terra_surface_init (src/Terra.c:1623-1657,1726-1764):
    obj[n] (-1 miss), tri[n], point3, surface47 = TerraShadingSurface as 47 floats */
 int terra_amd_unit_raycast ( HTerraScene scene, int n, const float* origins3, const float* dirs3, int* obj, int* tri, float* point3, float* surface47 );

@@ -19,6 +19,7 @@ hipError_t terra_unit_ray_aabb ( int n, const float* o, const float* d, const fl
 hipError_t terra_unit_watertight ( int n, const float* o, const float* d, const float* tris, int* hit, float* out8 );
 hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, const float* tris, int* hit, float* out4 );
 hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point );
+hipError_t terra_unit_bvh_traverse_fast ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point, uint32_t* nodes_visited );
 hipError_t terra_unit_raycast ( const DevScene& sc, int n, const float* o, const float* d, int* obj, int* tri, float* point, float* surface47 );
 hipError_t terra_unit_trace ( const DevScene& sc, int integrator, uint32_t bounces, int n, const float* o, const float* d,
                               const uint64_t* stateB, const uint64_t* incB, float* radiance, uint32_t* rand_calls );

@@ -393,7 +393,9 @@ static bool is_phong ( const TerraBSDF& b ) { return b.sample == terra_bsdf_phon
 // origin and a vertex: translating and shearing the vertices perturbs them by <= 4 u D per coordinate, the sign of an edge function
 // can be wrong only within ~2 u D of the edge, the slab test's t values carry <= 3 roundings (<= ~6 u D in position), the box itself
 // is rounded by <= u R: together < 16 u D, D <= 2 sqrt(3) R for origins and vertices inside [-R, R]^3, i.e. < 56 u R.
-// The check demands 128 u R <= 1e-4 (a factor 2.3 beyond that estimate): R <= 13.1 scene units, for the vertices (at commit) and for
+// The fast tree's boxes are traversed as (centre, half extent) (tree_build_device.hip): the new box contains the old one, and
+// t = (c - o) * inv -+ h * |inv| carries 4 roundings instead of 3 (<= ~8 u D): < 18 u D, i.e. < 63 u R.
+// The check demands 128 u R <= 1e-4 (a factor 2 beyond those estimates): R <= 13.1 scene units, for the vertices (at commit) and for
 // the camera position (per call). Scenes or cameras outside that range run in replica mode. tools/fuzz_vs_oracle.py scales scenes
 // through and beyond the limit (FUZZ_SCALE) to exercise both sides.
 static bool coords_within_margin ( const float* v, size_t n ) {
@@ -1143,6 +1145,13 @@ extern "C" int terra_amd_unit_bvh_traverse ( HTerraScene hs, int n, const float*
     Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n );
     auto f = u.out ( found, n ); auto pr = u.out ( prim, n ); auto pt = u.out ( point3, 3 * ( size_t ) n );
     return u.finish ( u.ok ? terra_unit_bvh_traverse ( s->dev, n, a, b, f, pr, pt ) : hipSuccess );
+}
+extern "C" int terra_amd_unit_bvh_traverse_fast ( HTerraScene hs, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point3, uint32_t* nodes_visited ) {
+    Scene* s = S ( hs ); int rc = need_scene ( s ); if ( rc ) return rc;
+    if ( !s->dev.fast_nodes ) return fail ( kTerraAmdErrBadArgument, "the committed scene has no fast tree (terra_amd_set_tree_mode 1, or 2 on a scene that is not LDS-resident)" );
+    Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n );
+    auto f = u.out ( found, n ); auto pr = u.out ( prim, n ); auto pt = u.out ( point3, 3 * ( size_t ) n ); auto nv = u.out ( nodes_visited, n );
+    return u.finish ( u.ok ? terra_unit_bvh_traverse_fast ( s->dev, n, a, b, f, pr, pt, nv ) : hipSuccess );
 }
 extern "C" int terra_amd_unit_raycast ( HTerraScene hs, int n, const float* o, const float* d, int* obj, int* tri, float* point3, float* surface47 ) {
     Scene* s = S ( hs ); int rc = need_scene ( s ); if ( rc ) return rc;

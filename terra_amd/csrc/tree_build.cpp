@@ -1,5 +1,8 @@
 // tree_build.cpp -- the two host-side tree builders (tree_build.h). Plain C++: no device code, no HIP calls.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -253,10 +256,15 @@ Built build ( std::vector<Prim>& prims ) {
         };
         todo.push_back ( { 0, mid, 0, 0, 1 } );
         todo.push_back ( { mid, n, 0, 1, 1 } );
+        const bool timing = getenv ( "TERRA_AMD_TIMING" ) != nullptr;
+        auto now = [] { return std::chrono::duration<double> ( std::chrono::steady_clock::now().time_since_epoch() ).count(); };
+        double t0 = now();
         run ( false, 0 );
         const int depth_cap = max_depth;
+        if ( timing ) { fprintf ( stderr, "[terra_amd timing]   fast tree pass 1 (binned splits)  %8.2f ms, %zu leaves to refine\n", ( now() - t0 ) * 1e3, leaves.size() ); t0 = now(); }
         todo.swap ( leaves );
         run ( true, depth_cap );
+        if ( timing ) fprintf ( stderr, "[terra_amd timing]   fast tree pass 2 (leaf refinement) %8.2f ms\n", ( now() - t0 ) * 1e3 );
         // ordered traversal with the near child kept in a register: one pending (far) child per level, plus the node in hand when a lane leaves the loop
         out.max_stack = max_depth + 1;
     }

@@ -103,6 +103,29 @@ hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, 
     return hipGetLastError();
 }
 
+// the fast tree's traversal (MODE 2) ray by ray, with the nodes each ray visited: same answers as k_bvh_traverse on any ray, axis-parallel ones included
+__global__ __launch_bounds__ ( 256 ) void k_bvh_traverse_fast ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point, uint32_t* nodes_visited ) {
+    extern __shared__ int lds_stack[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ( i >= n ) return;
+    Ray r = make_ray ( v3p ( o + 3 * i ), v3p ( d + 3 * i ) );
+    RayState s = ray_state_init ( r );
+    Counters c = counters_zero();
+    Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.lds_nodes = 0; T.lds_tris = 0;
+    T.stack = lds_stack + threadIdx.x; T.leaves = T.stack; T.leaf_cap = 0; T.stack_cap = sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack; T.faults = nullptr; T.cull = false;
+    ClosestRanked b = bvh_traverse_fast<1> ( T, r, s, c );
+    bool f = b.tri != 0xffffffffu;
+    found[i] = f ? 1 : 0;
+    prim[i] = f ? ( sc.fast_tris[b.tri].object | ( sc.fast_tris[b.tri].tri_in_object << 8 ) ) : 0u;
+    V3 pt = f ? r.o + r.d * b.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
+    point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
+    nodes_visited[i] = c.nodes;
+}
+hipError_t terra_unit_bvh_traverse_fast ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point, uint32_t* nodes_visited ) {
+    hipLaunchKernelGGL ( k_bvh_traverse_fast, UNIT_GRID ( n ), ( size_t ) ( sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack ) * 256 * sizeof ( int ), 0, sc, n, o, d, found, prim, point, nodes_visited );
+    return hipGetLastError();
+}
+
 __device__ void surface_to_floats ( const DevScene& sc, const Surface& sf, uint32_t object, float* q ) {
     Basis bs = make_basis ( sf.normal );
     q[0] = bs.r0[0]; q[1] = bs.r0[1]; q[2] = bs.r0[2]; q[3] = 0.f;

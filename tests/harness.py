@@ -182,6 +182,15 @@ class Unit:
                 point[i] = p.tuple()
         return found, prim, point
 
+    def bvh_traverse_fast(self, scene, o, d):
+        """the fast tree's traversal (device only): found, prim, point as bvh_traverse, plus nodes visited per ray"""
+        assert self.kind == "amd"
+        n = len(o)
+        found = np.zeros(n, np.int32); prim = np.zeros(n, np.uint32); point = np.zeros((n, 3), np.float32); nodes = np.zeros(n, np.uint32)
+        rc = self._f("bvh_traverse_fast", C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6)(scene, n, o.ctypes.data, d.ctypes.data, found.ctypes.data, prim.ctypes.data, point.ctypes.data, nodes.ctypes.data)
+        assert rc == 0, last_error()
+        return found, prim, point, nodes
+
     def raycast(self, scene, o, d):
         n = len(o)
         obj = np.zeros(n, np.int32); tri = np.zeros(n, np.int32); point = np.zeros((n, 3), np.float32); surf = np.zeros((n, 47), np.float32)

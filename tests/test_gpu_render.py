@@ -290,6 +290,37 @@ def test_hall_100k_goldens(H, L):
         assert H.same_bits(host["pixels"], g[f"i{integ}_pixels"]), integ
 
 
+def test_fast_tree_ray_by_ray_including_axis_parallel_rays(H, L):
+    """The fast tree's traversal must return the reference tree's hit for ANY ray -- its boxes are stored as centre + half extent
+    and tested with min/max that drop NaNs, so rays with zero direction components (infinite inverse direction) are the corner:
+    without the clamp in traverse_fast_resume they stay correct but visit every box along their line (one such ray cost 40 ms)."""
+    U = H.Unit("amd")
+    r = np.random.default_rng(77)
+    for name, d, box in (("hall", scenes.sponza_hall(64, 36, 1), ((-9.5, 0.3, -4.5), (9.5, 7.5, 4.5))), ("spheres", scenes.cornell_spheres(64, 36, 1), ((-0.9, 0.1, -0.9), (0.9, 1.9, 0.9)))):
+        L.clear_error()
+        scene = scenes.build_scene(L, d, tree_mode=1)
+        assert runtime.last_error() == "", runtime.last_error()
+        o, dd = H.scene_rays(5, 4096, box=box)
+        o = np.ascontiguousarray(o, np.float32); dd = np.ascontiguousarray(dd, np.float32)
+        # rays 1024.. : one or two direction components exactly zero; the last 256 start exactly on a vertex coordinate (origin in a box plane)
+        for i in range(1024, 4096):
+            k = r.integers(0, 3); dd[i, k] = 0.0
+            if i >= 2560: dd[i, (k + 1 + r.integers(0, 2)) % 3] = 0.0
+            if i >= 3584 and i % 2: dd[i] = -dd[i]
+        verts = np.concatenate([np.asarray(ob.triangles, np.float32).reshape(-1, 3) for ob in d.objects])
+        for i in range(3840, 4096): o[i, i % 3] = verts[r.integers(0, len(verts)), i % 3]
+        nrm = np.linalg.norm(dd, axis=1, keepdims=True); dd = np.ascontiguousarray(dd / np.where(nrm == 0, 1, nrm), np.float32)
+        f0, p0, pt0 = U.bvh_traverse(scene, o, dd)
+        f1, p1, pt1, nodes = U.bvh_traverse_fast(scene, o, dd)
+        assert np.array_equal(f0, f1), name
+        hit = f0 != 0
+        assert np.array_equal(p0[hit], p1[hit]) and H.same_bits(pt0[hit], pt1[hit]), name
+        assert hit.sum() > 2000, name
+        # the work of an axis-parallel ray stays in line with that of a general one (unclamped: ~20,000 nodes on the hall)
+        assert nodes[1024:].max() <= 4 * max(200, int(nodes[:1024].max())), (name, int(nodes[:1024].max()), int(nodes[1024:].max()))
+        L.scene_destroy(scene)
+
+
 def test_hall_full_hd_crop_vs_oracle_and_tiles(H, L, orc_lib, devmath_mode):
     """BASELINE.json configs[2] geometry at 1080p (reduced spp): a crop against the oracle, tile invariance"""
     d = scenes.sponza_hall(1920, 1080, 2, integrator=2)
