@@ -1,6 +1,11 @@
 // tree_build.cpp -- the two host-side tree builders (tree_build.h). Plain C++: no device code, no HIP calls.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <sched.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cfloat>
@@ -235,24 +240,72 @@ Built build ( std::vector<Prim>& prims ) {
         // further where the surface-area estimate pays -- but never below the depth pass 1 reached, because the traversal stack
         // (one KB of LDS per entry and block) is sized by the depth and the kernel's occupancy hangs on it
         std::vector<Task> leaves;
+        // Subtrees are independent (disjoint triangle ranges, disjoint child slots), so large scenes are built by several threads:
+        // a shared list hands out tasks, a thread keeps a subtree to itself once its range is below 8192 triangles. Nodes come from
+        // a preallocated array through an atomic counter (a binary tree over n triangles has fewer than n inner nodes); which thread
+        // built what does not show in the result, because the array is renumbered depth first below.
+        out.nodes.resize ( ( size_t ) n + 1 + 2 * 64 * 16 );
+        std::atomic<uint32_t> next_node ( 1 );
+        std::atomic<int> depth_seen ( max_depth );
+        int n_threads = 1;
+        if ( n >= 20000 ) {
+            cpu_set_t set; CPU_ZERO ( &set );
+            int cpus = sched_getaffinity ( 0, sizeof set, &set ) == 0 ? CPU_COUNT ( &set ) : ( int ) std::thread::hardware_concurrency();
+            if ( const char* e = getenv ( "TERRA_AMD_BUILD_THREADS" ) ) cpus = atoi ( e );
+            n_threads = std::max ( 1, std::min ( cpus, 16 ) );
+        }
         auto run = [&] ( bool refine, int depth_cap ) {
-            while ( !todo.empty() ) {
-                Task t = todo.back(); todo.pop_back();
-                max_depth = std::max ( max_depth, t.depth );
-                TerraAABB b = bounds ( t.lo, t.hi );
-                int m = 0;
-                if ( ( refine && t.depth >= depth_cap ) || !split ( t.lo, t.hi, m, refine ) ) {
-                    set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, make_leaf ( t.lo, t.hi ) );
-                    if ( !refine && t.hi - t.lo > 1 ) leaves.push_back ( t );
-                    continue;
+            std::mutex mu; std::condition_variable cv; int busy = 0;
+            std::vector<std::vector<Task>> kept ( ( size_t ) n_threads );
+            std::vector<double> busy_s ( ( size_t ) n_threads, 0.0 ); std::vector<int> taken ( ( size_t ) n_threads, 0 );
+            auto worker = [&] ( int tid ) {
+                std::vector<Task> local, mine;
+                uint32_t chunk_next = 0, chunk_end = 0;          // node indices are taken 64 at a time, so threads do not write to neighbouring cache lines
+                for ( ;; ) {
+                    {
+                        std::unique_lock<std::mutex> lk ( mu );
+                        cv.wait ( lk, [&] { return !todo.empty() || busy == 0; } );
+                        if ( todo.empty() ) { kept[ ( size_t ) tid].swap ( mine ); return; }
+                        // one big range at a time, or a batch of small ones (pass 2 hands out tens of thousands of 2-4 triangle ranges)
+                        do { local.push_back ( todo.back() ); todo.pop_back(); } while ( !todo.empty() && local.size() < 512 && local.back().hi - local.back().lo <= 64 && todo.back().hi - todo.back().lo <= 64 );
+                        ++busy;
+                    }
+                    const auto tb = std::chrono::steady_clock::now(); ++taken[ ( size_t ) tid];
+                    int deepest = 0;
+                    while ( !local.empty() ) {
+                        Task t = local.back(); local.pop_back();
+                        deepest = std::max ( deepest, t.depth );
+                        TerraAABB b = bounds ( t.lo, t.hi );
+                        int m = 0;
+                        if ( ( refine && t.depth >= depth_cap ) || !split ( t.lo, t.hi, m, refine ) ) {
+                            set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, make_leaf ( t.lo, t.hi ) );
+                            if ( !refine && t.hi - t.lo > 1 ) mine.push_back ( t );
+                            continue;
+                        }
+                        if ( chunk_next == chunk_end ) { chunk_next = next_node.fetch_add ( 64 ); chunk_end = chunk_next + 64; }
+                        const uint32_t idx = chunk_next++;
+                        memset ( &out.nodes[idx], 0, sizeof ( DevNode ) );
+                        set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, idx );
+                        const Task l = { t.lo, m, ( int ) idx, 0, t.depth + 1 }, r = { m, t.hi, ( int ) idx, 1, t.depth + 1 };
+                        if ( n_threads > 1 && t.hi - t.lo > 8192 ) {
+                            { std::lock_guard<std::mutex> lk ( mu ); todo.push_back ( l ); todo.push_back ( r ); }
+                            cv.notify_all();
+                        } else { local.push_back ( l ); local.push_back ( r ); }
+                    }
+                    int seen = depth_seen.load();
+                    while ( deepest > seen && !depth_seen.compare_exchange_weak ( seen, deepest ) ) {}
+                    busy_s[ ( size_t ) tid] += std::chrono::duration<double> ( std::chrono::steady_clock::now() - tb ).count();
+                    { std::lock_guard<std::mutex> lk ( mu ); --busy; }
+                    cv.notify_all();
                 }
-                uint32_t idx = ( uint32_t ) out.nodes.size();
-                out.nodes.push_back ( DevNode() );
-                memset ( &out.nodes.back(), 0, sizeof ( DevNode ) );
-                set_child ( out.nodes[ ( size_t ) t.node], t.slot, b, idx );
-                todo.push_back ( { t.lo, m, ( int ) idx, 0, t.depth + 1 } );
-                todo.push_back ( { m, t.hi, ( int ) idx, 1, t.depth + 1 } );
-            }
+            };
+            std::vector<std::thread> pool;
+            for ( int k = 1; k < n_threads; ++k ) pool.emplace_back ( worker, k );
+            worker ( 0 );
+            for ( std::thread& th : pool ) th.join();
+            for ( const std::vector<Task>& v : kept ) leaves.insert ( leaves.end(), v.begin(), v.end() );
+            max_depth = depth_seen.load();
+            if ( getenv ( "TERRA_AMD_TIMING" ) && n_threads > 1 ) for ( int k = 0; k < n_threads; ++k ) fprintf ( stderr, "[terra_amd timing]     thread %d: %d tasks, %.2f ms busy\n", k, taken[ ( size_t ) k], busy_s[ ( size_t ) k] * 1e3 );
         };
         todo.push_back ( { 0, mid, 0, 0, 1 } );
         todo.push_back ( { mid, n, 0, 1, 1 } );
@@ -261,10 +314,11 @@ Built build ( std::vector<Prim>& prims ) {
         double t0 = now();
         run ( false, 0 );
         const int depth_cap = max_depth;
-        if ( timing ) { fprintf ( stderr, "[terra_amd timing]   fast tree pass 1 (binned splits)  %8.2f ms, %zu leaves to refine\n", ( now() - t0 ) * 1e3, leaves.size() ); t0 = now(); }
+        if ( timing ) { fprintf ( stderr, "[terra_amd timing]   fast tree pass 1 (binned splits)  %8.2f ms on %d threads, %zu leaves to refine\n", ( now() - t0 ) * 1e3, n_threads, leaves.size() ); t0 = now(); }
         todo.swap ( leaves );
         run ( true, depth_cap );
         if ( timing ) fprintf ( stderr, "[terra_amd timing]   fast tree pass 2 (leaf refinement) %8.2f ms\n", ( now() - t0 ) * 1e3 );
+        out.nodes.resize ( next_node.load() );
         // ordered traversal with the near child kept in a register: one pending (far) child per level, plus the node in hand when a lane leaves the loop
         out.max_stack = max_depth + 1;
     }

@@ -4,7 +4,7 @@
 // A linear BVH (Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"): 30-bit Morton
 // codes of the box centres made unique by the triangle index, one radix sort (hipCUB), every inner node's range and split
 // found independently from the sorted keys, boxes fitted bottom-up with one atomic counter per node, subtrees of at most
-// TERRA_FAST_LEAF_MAX triangles collapsed into leaves, the surviving nodes compacted by a prefix sum. The result has the
+// TERRA_LBVH_LEAF_MAX triangles collapsed into leaves, the surviving nodes compacted by a prefix sum. The result has the
 // layout the host builder (tree_build.cpp, binned SAH) produces -- DevNode array with the root at 0, leaf word =
 // DEV_CHILD_LEAF | (count - 1) << 27 | first, triangle soup in leaf order with the reference visit rank in DevTri::pad --
 // so terra_render_kernel<.., MODE 2, ..> traverses either. Boxes are the same +-1e-4 triangle boxes as the host's and
@@ -17,8 +17,8 @@
 #include "dev_types.h"
 #include "kernels.h"
 
-#ifndef TERRA_FAST_LEAF_MAX
-#define TERRA_FAST_LEAF_MAX 4
+#ifndef TERRA_LBVH_LEAF_MAX
+#define TERRA_LBVH_LEAF_MAX 2      // (hall at 97k / 289k / 650k triangles, 16 spp: 4 -> 1,064 / 970 / 897 Msamples/s, 2 -> 1,150 / 1,037 / 961, 1 -> 1,067 / 987 / 790)
 #endif
 
 namespace {
@@ -121,7 +121,7 @@ __global__ void k_fit ( const unsigned long long* keys, const Box* prim_boxes, i
 __global__ void k_keep ( const int2* range, int n, uint32_t* keep ) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if ( i >= n - 1 ) return;
-    keep[i] = ( i == 0 || range[i].y - range[i].x + 1 > TERRA_FAST_LEAF_MAX ) ? 1u : 0u;
+    keep[i] = ( i == 0 || range[i].y - range[i].x + 1 > TERRA_LBVH_LEAF_MAX ) ? 1u : 0u;
 }
 __device__ __forceinline__ void put_child ( DevNode& nd, int slot, const Box& b, uint32_t word ) {
     float* mn = slot == 0 ? nd.min0 : nd.min1; float* mx = slot == 0 ? nd.max0 : nd.max1;
@@ -162,9 +162,9 @@ struct Scratch {
 
 #define TB_TRY(expr) do { hipError_t e_ = ( expr ); if ( e_ != hipSuccess ) return e_; } while ( 0 )
 
-// tris / rank / out_nodes (capacity n - 1) / out_tris (capacity n) are device pointers; n > TERRA_FAST_LEAF_MAX.
+// tris / rank / out_nodes (capacity n - 1) / out_tris (capacity n) are device pointers; n > TERRA_LBVH_LEAF_MAX.
 hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream ) {
-    if ( n <= TERRA_FAST_LEAF_MAX || n > 0x07ffffffu ) return hipErrorInvalidValue;
+    if ( n <= TERRA_LBVH_LEAF_MAX || n > 0x07ffffffu ) return hipErrorInvalidValue;
     const size_t N = n;
     auto al = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
     size_t off = 0;
