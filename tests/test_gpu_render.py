@@ -434,6 +434,24 @@ def test_fast_tree_built_on_the_device(H, L):
     L.scene_destroy(scene)
 
 
+def test_host_fast_tree_build_does_not_depend_on_its_threads(H, L, monkeypatch):
+    """the host builder hands subtrees to several threads (tree_build.cpp); the tree -- hence the work a render does -- must be the same whatever the schedule"""
+    import torch
+    d = scenes.sponza_hall(160, 90, 2, integrator=0)
+    got = []
+    for threads in ("1", "3", None, None):
+        if threads is None: monkeypatch.delenv("TERRA_AMD_BUILD_THREADS", raising=False)
+        else: monkeypatch.setenv("TERRA_AMD_BUILD_THREADS", threads)
+        scene = scenes.build_scene(L, d, tree_mode=1, tree_builder=0)
+        fb = runtime.DeviceFramebuffer(d.width, d.height)
+        runtime.render_device(L, scenes.camera_of(d), scene, fb); torch.cuda.synchronize()
+        st = runtime.Stats(); runtime.check(L.get_stats(scene, C.byref(st))); st = st.as_dict()
+        got.append((fb.pixels_host().copy(), st["nodes"], st["tri_tests"], st["rays"]))
+        L.scene_destroy(scene)
+    for g in got[1:]:
+        assert same(H, g[0], got[0][0]) and g[1:] == got[0][1:], (g[1:], got[0][1:])
+
+
 def test_fast_tree_hall_goldens_and_work(H, L):
     """the fast tree reproduces the REFERENCE's image of the 97k-triangle hall with a fraction of the traversal work"""
     g = G(H, "render_hall")
