@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "hall or fast or tree or config3 or spheres or fuzz or axis or threads" > gpurun_out/r02_j39_tests.log 2>&1; echo "tests rc $?"; tail -3 gpurun_out/r02_j39_tests.log
+for wl in "hall_1080p_256spp --spp 64 --sample-split 1" "spheres_1080p_1024spp --spp 128 --sample-split 8" "hall_1080p_256spp --spp 32 --sample-split 1 --integrator direct" "hall_1080p_256spp --spp 32 --sample-split 1 --integrator mis" "hall_1080p_256spp --sample-split 1"; do
+    timeout -k 10 200 python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-workloads 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['counters_per_launch']; print('$wl', 'kernel_ms', d['roofline']['kernel_ms'], 'Msamples/s', d['value'], 'nodes/ray %.2f' % (c['nodes']/c['rays']))"
+done
