@@ -240,9 +240,6 @@ extern "C" void terra_framebuffer_destroy ( TerraFramebuffer* fb ) {
 // ------------------------------------------------------------------------------
 struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 
-#ifndef TERRA_FAST_CENTER_EXTENT
-#define TERRA_FAST_CENTER_EXTENT 1
-#endif
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
 struct Scene {
     TerraSceneOptions opts, new_opts;
@@ -670,20 +667,6 @@ static int upload_scene ( Scene* s ) {
     HIP_TRY ( hipMemcpy ( base + o_lights, lights.data(), lights.size() * sizeof ( DevLight ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( base + o_area, tri_area.data(), tri_area.size() * sizeof ( float ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     if ( !fnodes.empty() ) {
-        if ( TERRA_FAST_CENTER_EXTENT && getenv ( "TERRA_AMD_HOST_CONVERT" ) ) {
-            for ( DevNode& nd : fnodes ) for ( int b = 0; b < 2; ++b ) {
-                float* mn = b ? nd.min1 : nd.min0; float* mx = b ? nd.max1 : nd.max0;
-                for ( int a = 0; a < 3; ++a ) {
-                    const float lo = mn[a], hi = mx[a];
-                    const float c = 0.5f * ( lo + hi );
-                    const double hd = std::max ( ( double ) c - ( double ) lo, ( double ) hi - ( double ) c );
-                    float h = ( float ) hd;
-                    if ( ( double ) h < hd ) h = nextafterf ( h, INFINITY );
-                    if ( !( lo <= hi ) ) h = -1.f;
-                    mn[a] = c; mx[a] = h;
-                }
-            }
-        }
         HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
@@ -713,7 +696,7 @@ static int upload_scene ( Scene* s ) {
             phase ( "  read back + containment check", t_phase );
         }
     }
-    if ( TERRA_FAST_CENTER_EXTENT && have_fast && s->fast_nodes && !( getenv ( "TERRA_AMD_HOST_CONVERT" ) && !s->fast_on_device ) ) {       // boxes as (centre, half extent): what the kernels traverse; everything above checked the (min, max) form
+    if ( have_fast && s->fast_nodes ) {       // boxes as (centre, half extent): what the kernels traverse; everything above checked the (min, max) form
         hipError_t e = terra_fast_nodes_center_extent ( ( DevNode* ) ( base + o_fn ), s->fast_nodes, nullptr );
         if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "fast tree conversion: %s", hipGetErrorString ( e ) );
     }

@@ -452,19 +452,7 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 // reference tree's test this one only has to be CONSERVATIVE (never reject a box that holds a triangle the ray hits; DESIGN.md
 // "Traversal policy"): near / far per axis come out of one subtraction and one addition, v_max3 / v_min3 drop a NaN (0 x inf or
 // inf - inf: a ray parallel to a box plane), which only widens the interval.
-#ifndef TERRA_FAST_CENTER_EXTENT
-#define TERRA_FAST_CENTER_EXTENT 1
-#endif
 TD bool slab_enter ( V3 c, V3 h, const Ray& r, float& t_enter ) {
-    if ( !TERRA_FAST_CENTER_EXTENT ) {          // (min, max) boxes: A/B builds only
-        float t1x = ( c.x - r.o.x ) * r.inv.x, t2x = ( h.x - r.o.x ) * r.inv.x;
-        float t1y = ( c.y - r.o.y ) * r.inv.y, t2y = ( h.y - r.o.y ) * r.inv.y;
-        float t1z = ( c.z - r.o.z ) * r.inv.z, t2z = ( h.z - r.o.z ) * r.inv.z;
-        float tmin = __builtin_fmaxf ( __builtin_fmaxf ( __builtin_fminf ( t1x, t2x ), __builtin_fminf ( t1y, t2y ) ), __builtin_fminf ( t1z, t2z ) );
-        float tmax = __builtin_fminf ( __builtin_fminf ( __builtin_fmaxf ( t1x, t2x ), __builtin_fmaxf ( t1y, t2y ) ), __builtin_fmaxf ( t1z, t2z ) );
-        t_enter = __builtin_fmaxf ( tmin, 0.f );
-        return tmax > t_enter;
-    }
     const float tcx = ( c.x - r.o.x ) * r.inv.x, hx = h.x * __builtin_fabsf ( r.inv.x );
     const float tcy = ( c.y - r.o.y ) * r.inv.y, hy = h.y * __builtin_fabsf ( r.inv.y );
     const float tcz = ( c.z - r.o.z ) * r.inv.z, hz = h.z * __builtin_fabsf ( r.inv.z );

@@ -131,7 +131,7 @@ void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nod
 #define TERRA_FAST_LEAF_MAX 4
 #endif
 #ifndef TERRA_FAST_SAH_TRI_COST
-#define TERRA_FAST_SAH_TRI_COST 3.0f
+#define TERRA_FAST_SAH_TRI_COST 1.0f      // measured, not derived: hall / sphere scene render 81.4 / 65.5 ms at 1.0, 82.1 / 66.7 at 3.0 (profiles/r02_measurements/ab_fast_tree_loop.log)
 #endif
 namespace fastbvh {
 
@@ -173,8 +173,7 @@ Built build ( std::vector<Prim>& prims ) {
         if ( cnt <= TERRA_FAST_LEAF_MAX ) {
             if ( !refine ) return false;
             // a range that may become a leaf: exact sweep over the three axes, split only if the surface-area estimate says the extra
-            // node step is cheaper than the triangle steps it saves. TERRA_FAST_SAH_TRI_COST = cost of a triangle step in node steps as the
-            // kernel runs them (350 vs 160 issue cycles, at 0.3 vs 0.46 lane utilisation on the hall: profiles/r02_measurements/ab_fast_tree_loop.log)
+            // node step is cheaper than the triangle steps it saves (TERRA_FAST_SAH_TRI_COST = cost of a triangle step in node steps)
             const float pa = half_area ( bounds ( lo, hi ) );
             float best = ( float ) cnt * TERRA_FAST_SAH_TRI_COST; int best_axis = -1, best_k = 0;
             for ( int a = 0; a < 3 && pa > 0.f; ++a ) {
@@ -257,7 +256,6 @@ Built build ( std::vector<Prim>& prims ) {
         auto run = [&] ( bool refine, int depth_cap ) {
             std::mutex mu; std::condition_variable cv; int busy = 0;
             std::vector<std::vector<Task>> kept ( ( size_t ) n_threads );
-            std::vector<double> busy_s ( ( size_t ) n_threads, 0.0 ); std::vector<int> taken ( ( size_t ) n_threads, 0 );
             auto worker = [&] ( int tid ) {
                 std::vector<Task> local, mine;
                 uint32_t chunk_next = 0, chunk_end = 0;          // node indices are taken 64 at a time, so threads do not write to neighbouring cache lines
@@ -270,7 +268,6 @@ Built build ( std::vector<Prim>& prims ) {
                         do { local.push_back ( todo.back() ); todo.pop_back(); } while ( !todo.empty() && local.size() < 512 && local.back().hi - local.back().lo <= 64 && todo.back().hi - todo.back().lo <= 64 );
                         ++busy;
                     }
-                    const auto tb = std::chrono::steady_clock::now(); ++taken[ ( size_t ) tid];
                     int deepest = 0;
                     while ( !local.empty() ) {
                         Task t = local.back(); local.pop_back();
@@ -294,7 +291,6 @@ Built build ( std::vector<Prim>& prims ) {
                     }
                     int seen = depth_seen.load();
                     while ( deepest > seen && !depth_seen.compare_exchange_weak ( seen, deepest ) ) {}
-                    busy_s[ ( size_t ) tid] += std::chrono::duration<double> ( std::chrono::steady_clock::now() - tb ).count();
                     { std::lock_guard<std::mutex> lk ( mu ); --busy; }
                     cv.notify_all();
                 }
@@ -305,7 +301,6 @@ Built build ( std::vector<Prim>& prims ) {
             for ( std::thread& th : pool ) th.join();
             for ( const std::vector<Task>& v : kept ) leaves.insert ( leaves.end(), v.begin(), v.end() );
             max_depth = depth_seen.load();
-            if ( getenv ( "TERRA_AMD_TIMING" ) && n_threads > 1 ) for ( int k = 0; k < n_threads; ++k ) fprintf ( stderr, "[terra_amd timing]     thread %d: %d tasks, %.2f ms busy\n", k, taken[ ( size_t ) k], busy_s[ ( size_t ) k] * 1e3 );
         };
         todo.push_back ( { 0, mid, 0, 0, 1 } );
         todo.push_back ( { mid, n, 0, 1, 1 } );
