@@ -62,3 +62,20 @@ def test_two_gloo_ranks_on_one_gpu_started_by_bench_itself():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 2 and out["sharded_equals_unsharded"] is True and out["dist_backend"] == "gloo" and out["config"]["parallelism"] == "tiles%2"
+
+
+def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
+    """roofline.frac = SQ_INSTS_VALU / kernel time / (1024 SIMDs x 2.4 GHz / 2) -- or fabric bytes / kernel time / 8 TB/s when that is larger -- from profiles/r02_pmc.json"""
+    import bench
+    pmc = json.loads((ROOT / "profiles" / "r02_pmc.json").read_text())
+    assert len({r["source_digest"] for r in pmc.values()}) == 1            # one profiling session, one set of kernel sources
+    for key, rec in pmc.items():
+        r = bench.roofline(key, rec["counters_per_launch"], rec["kernel_ms"], "cornell" in key, 1)
+        t = rec["kernel_ms"] * 1e-3
+        valu = rec["SQ_INSTS_VALU"] / t / 1e9 / (1024 * 2.4 / 2)
+        fabric = rec["hbm_bytes_per_launch"] / t / 1e9 / 8000.0
+        assert r["pmc_record"] == key and 0 < r["frac"] <= 1 and r["bound"] in ("valu", "l2_fabric")
+        assert abs(r["frac"] - max(valu, fabric)) < 1e-3 and (r["bound"] == "valu") == (valu >= fabric)
+        assert 0 < r["lane_util"] <= 1 and r["algorithmic_gbs"] > 0
+    head = bench.roofline("cornell_1080p_512spp|tree=auto|integrator=simple|split=8", pmc["cornell_1080p_512spp|tree=auto|integrator=simple|split=8"]["counters_per_launch"], 65.7, True, 1)
+    assert head["bound"] == "valu" and 0.6 < head["frac"] < 0.8
