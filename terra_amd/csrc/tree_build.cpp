@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <system_error>
 #include <sched.h>
 #include <cstdio>
 #include <cstdlib>
@@ -296,7 +297,10 @@ Built build ( std::vector<Prim>& prims ) {
                 }
             };
             std::vector<std::thread> pool;
-            for ( int k = 1; k < n_threads; ++k ) pool.emplace_back ( worker, k );
+            for ( int k = 1; k < n_threads; ++k ) {
+                try { pool.emplace_back ( worker, k ); }
+                catch ( ... ) { break; }                      // no more threads to be had: the ones running (at least this one) share the list
+            }
             worker ( 0 );
             for ( std::thread& th : pool ) th.join();
             for ( const std::vector<Task>& v : kept ) leaves.insert ( leaves.end(), v.begin(), v.end() );
