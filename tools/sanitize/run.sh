@@ -14,3 +14,9 @@ gcc -std=gnu11 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -pthread -fsanitize
 export LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0
 python3 $ROOT/tools/sanitize/drive_host.py $OUT/libterra_host_asan.so 2>&1 | grep -v "no HIP device" | tail -5
 python3 $ROOT/tools/sanitize/drive_oracle.py $OUT/liboracle_asan.so 2>&1 | tail -5
+# ThreadSanitizer over the same host layer (the fast tree's host builder is threaded)
+unset LD_PRELOAD ASAN_OPTIONS
+g++ -std=c++17 -O1 -g -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/terra_amd/csrc -fsanitize=thread -fno-omit-frame-pointer -ffp-contract=off -w \
+    -shared -o $OUT/libterra_host_tsan.so $ROOT/terra_amd/csrc/scene_host.cpp $ROOT/terra_amd/csrc/tree_build.cpp $ROOT/tools/sanitize/stub_launchers.cpp -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+LD_PRELOAD=$(gcc -print-file-name=libtsan.so) TSAN_OPTIONS="report_signal_unsafe=0 exitcode=0" python3 $ROOT/tools/sanitize/drive_host.py $OUT/libterra_host_tsan.so 2>&1 | grep -v "no HIP device" > $OUT/tsan.log || true
+echo "tsan warnings: $(grep -c 'WARNING: ThreadSanitizer' $OUT/tsan.log)"

@@ -19,3 +19,11 @@ hipError_t terra_unit_bsdf ( int, int, float*, const float*, const float*, float
 hipError_t terra_unit_camera ( const DevRenderParams&, int, const uint32_t*, const float*, float* ) { return hipErrorNoDevice; }
 hipError_t terra_unit_tonemap ( int, float, int, float* ) { return hipErrorNoDevice; }
 hipError_t terra_unit_math ( int, int, const float*, const float*, float* ) { return hipErrorNoDevice; }
+hipError_t terra_unit_bvh_traverse_fast ( const DevScene&, int, const float*, const float*, int*, uint32_t*, float*, uint32_t* ) { return hipErrorNoDevice; }
+hipError_t terra_unit_stratified ( const uint32_t*, int, int, int, int, float* ) { return hipErrorNoDevice; }
+hipError_t terra_unit_halton ( int, int, float* ) { return hipErrorNoDevice; }
+hipError_t terra_unit_distribution_1d ( const float*, uint32_t, float*, float*, uint32_t*, const float*, int, float*, float*, uint32_t* ) { return hipErrorNoDevice; }
+hipError_t terra_unit_distribution_2d ( const float*, uint32_t, uint32_t, float*, float*, float*, uint32_t*, const float*, int, float*, float* ) { return hipErrorNoDevice; }
+hipError_t terra_build_fast_tree_device ( const DevTri*, const uint32_t*, uint32_t, DevNode*, DevTri*, uint32_t*, int*, hipStream_t ) { return hipErrorNoDevice; }
+hipError_t terra_fast_nodes_center_extent ( DevNode*, uint32_t, hipStream_t ) { return hipErrorNoDevice; }
+void terra_plan_fast_tree ( DevRenderParams& p ) { p.lds_mode = 2; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = 1; p.lds_nodes = 0; }
