@@ -79,5 +79,6 @@ for it in range(n_iter):
         bad += 1; print("MISMATCH", dict(it=it, tris=n, W=W, H=H, integ=integ, split=split, spp=spp, bounces=d.bounces, tonemap=d.tonemap, env=d.environment_lighting, vs_oracle=ok0, fast_vs_ref=ok1, auto_vs_ref=ok2,
                                          kinds=[o.material.kind for o in d.objects]))
     fo.destroy(); orc.scene_destroy(so); orc.scene_destroy(sc)
+    if (it + 1) % 1000 == 0: print(f"  {it + 1} cases, {bad} mismatches so far", file=sys.stderr, flush=True)      # (a long silent run on the GPU box is taken for a hang)
 print(f"{n_iter} cases at scale {SCALE:g}, {bad} mismatches, {faults} bounds faults, automatic mode chose {decided}, last error: '{runtime.last_error()}'")
 sys.exit(1 if bad or faults else 0)
