@@ -103,6 +103,12 @@ struct DevScene {
     const DevTri*      fast_tris;
     uint32_t n_fast_nodes;
     int32_t  fast_max_stack;
+    // scenes outside the coordinate range of the containment proof (DESIGN.md "Reachability"): the fast tree (boxes inflated to the rounding bound) finds the
+    // candidates, and one is accepted only if the REFERENCE traversal would have reached it: ref_parent[node] = parent << 1 | child slot (node 0 = root),
+    // fast_leaf_parent[i] = the reference node whose leaf child fast triangle i is
+    const uint32_t*    ref_parent;
+    const uint32_t*    fast_leaf_parent;
+    uint32_t           reach;
     // environment lighting (terra_amd_set_environment_lighting; off = the reference's behaviour):
     // 0 off, 1 constant env_color, 2 lat-long lookup of textures[env_tex] by ray direction
     int32_t  env_mode;

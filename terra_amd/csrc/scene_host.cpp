@@ -240,6 +240,10 @@ extern "C" void terra_framebuffer_destroy ( TerraFramebuffer* fb ) {
 // ------------------------------------------------------------------------------
 struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 
+#ifndef TERRA_REACH_CAMERA_FACTOR
+#define TERRA_REACH_CAMERA_FACTOR 8.f
+#endif
+#define TERRA_REACH_MAX_COORD 1e6f       // beyond it (c - o) x 2^100 (the fast tree's clamped slab test) approaches the binary32 range: replica
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
 struct Scene {
     TerraSceneOptions opts, new_opts;
@@ -265,6 +269,8 @@ struct Scene {
     int tree_builder = 0;               // terra_amd_set_tree_builder: 0 = host (binned SAH), 1 = device (LBVH, tree_build_device.hip)
     bool fast_on_device = false;        // the fast tree of the last upload was built on the device
     bool cull_ok = false;               // leaf-box cull allowed for this scene (subject to the per-call camera check)
+    bool reach = false;                 // outside the coordinate range: fast tree + reference reachability check (camera within reach_limit, checked per call)
+    float reach_limit = 0.f;
     float coord_max = 0.f;              // largest |coordinate| of any vertex
     std::string tree_note;              // why the automatic mode chose what it chose
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
@@ -573,14 +579,24 @@ static int upload_scene ( Scene* s ) {
             } else { d.child[c] = DEV_CHILD_EMPTY; d.prim[c] = 0; }
         }
     }
+    // test hook (tests/test_gpu_render.py "reachability"): shrink the DEVICE copy of the reference tree's boxes, so that the reference traversal -- as the device replays
+    // it -- misses triangles the watertight test would hit, the situation the reachability replay exists for and that float rounding alone produces too rarely to test
+    if ( const char* e = getenv ( "TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES" ) ) {
+        const float g = ( float ) atof ( e );
+        for ( DevNode& d : nodes ) for ( int a = 0; a < 3; ++a ) {
+            if ( d.max0[a] - d.min0[a] > 2.f * g ) { d.min0[a] += g; d.max0[a] -= g; }
+            if ( d.max1[a] - d.min1[a] > 2.f * g ) { d.min1[a] += g; d.max1[a] -= g; }
+        }
+    }
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
-    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device;
+    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device, ref_parent, fast_leaf_parent;
     s->fast_nodes = 0; s->fast_max_stack = 1; s->fast_on_device = false;
     // traversal policy (see Scene::tree_mode and the containment check above)
     s->coord_max = 0.f; s->cull_ok = false; s->tree_note.clear();
     bool margin_ok = true;
     for ( size_t j = 0; j < nobj && margin_ok; ++j ) margin_ok = coords_within_margin ( &s->objects[j].triangles[0].a.x, s->objects[j].triangles_count * 9 );
-    for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count * 9; ++i ) { float v = fabsf ( ( &s->objects[j].triangles[0].a.x ) [i] ); if ( v > s->coord_max ) s->coord_max = v; }
+    bool coords_finite = true;
+    for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count * 9; ++i ) { float v = fabsf ( ( &s->objects[j].triangles[0].a.x ) [i] ); if ( v > s->coord_max ) s->coord_max = v; if ( !std::isfinite ( v ) ) coords_finite = false; }
     const bool resident = terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack );
     bool auto_ok = false;
     if ( s->tree_mode == 2 ) {
@@ -591,7 +607,19 @@ static int upload_scene ( Scene* s ) {
         else auto_ok = true;
     } else s->tree_note = s->tree_mode == 0 ? "replica traversal requested" : "fast tree requested";
     s->cull_ok = auto_ok;
-    s->use_fast = s->tree_mode == 1 || ( auto_ok && !resident );
+    // Outside the range the reference's own slab test can numerically miss a box whose triangle the watertight test would hit, so the containment
+    // shortcut is gone -- but not the fast tree: with its boxes inflated to the rounding bound it still finds every triangle the watertight test accepts,
+    // and a candidate is accepted only if the reference traversal would have reached it (its inner ancestors' slab tests, replayed exactly). Rays may start
+    // up to TERRA_REACH_CAMERA_FACTOR x the scene's largest coordinate from the origin (the camera, checked per call); margin = 128 u x that limit.
+    s->reach = false; s->reach_limit = 0.f;
+    float reach_margin = 0.f;
+    if ( s->tree_mode == 2 && !auto_ok && !margin_ok && ntri >= 2 && !resident && coords_finite && s->coord_max <= TERRA_REACH_MAX_COORD ) {
+        s->reach = true; s->reach_limit = TERRA_REACH_CAMERA_FACTOR * s->coord_max;
+        reach_margin = 128.f * 5.9604645e-8f * s->reach_limit;
+        char b[200]; snprintf ( b, sizeof b, "largest coordinate %.6g exceeds %.1f: fast tree with boxes inflated by %.3g and the reference's reachability replayed per accepted hit", ( double ) s->coord_max, ( double ) TERRA_CULL_MAX_COORD, ( double ) reach_margin );
+        s->tree_note = b;
+    }
+    s->use_fast = s->tree_mode == 1 || ( auto_ok && !resident ) || s->reach;
     if ( s->use_fast ) {
         // rank of every soup triangle in the reference traversal's leaf visit order (all boxes hit)
         std::vector<uint32_t> rank ( ntri ? ntri : 1, 0 );
@@ -605,7 +633,7 @@ static int upload_scene ( Scene* s ) {
                 }
             }
         }
-        s->fast_on_device = s->tree_builder == 1 && ntri > 64 && terra_amd_device_count() > 0;
+        s->fast_on_device = s->tree_builder == 1 && ntri > 64 && terra_amd_device_count() > 0 && !s->reach;      // (the inflated boxes of the reachability mode are the host builder's)
         if ( s->fast_on_device ) {
             // built after the upload, from the soup already in HBM; the host only supplies the reference visit ranks
             rank_for_device.swap ( rank );
@@ -614,6 +642,7 @@ static int upload_scene ( Scene* s ) {
             for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count; ++i ) {
                 fastbvh::Prim& q = prims[s->first_tri[j] + i];
                 q.box = bvh::empty_box(); bvh::grow_by_triangle ( q.box, s->objects[j].triangles[i] );
+                if ( s->reach && reach_margin > 1e-4f ) { const float g = reach_margin - 1e-4f; q.box.min.x -= g; q.box.min.y -= g; q.box.min.z -= g; q.box.max.x += g; q.box.max.y += g; q.box.max.z += g; }
                 q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
                 q.soup = ( uint32_t ) ( s->first_tri[j] + i );
             }
@@ -631,9 +660,20 @@ static int upload_scene ( Scene* s ) {
             fnodes.swap ( built.nodes );
             ftris.resize ( ntri ? ntri : 1 );
             for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
+            if ( s->reach ) {          // parent links of the reference tree (device numbering) and, per fast triangle, the reference node it hangs from
+                ref_parent.assign ( nodes.size(), 0u ); std::vector<uint32_t> leaf_parent ( ntri, 0u );
+                for ( size_t k = 0; k < nodes.size(); ++k ) for ( int c = 0; c < 2; ++c ) {
+                    const uint32_t w = nodes[k].child[c];
+                    if ( w == DEV_CHILD_EMPTY ) continue;
+                    if ( w & DEV_CHILD_LEAF ) leaf_parent[w & 0x7fffffffu] = ( uint32_t ) k; else ref_parent[w] = ( uint32_t ) ( k << 1 ) | ( uint32_t ) c;
+                }
+                fast_leaf_parent.resize ( ntri );
+                for ( size_t k = 0; k < built.order.size(); ++k ) fast_leaf_parent[k] = leaf_parent[built.order[k]];
+            }
             s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
         }
     }
+    if ( s->tree_mode == 2 && s->reach && !s->use_fast ) { s->reach = false; }
     if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
     // one blob, 256-byte aligned sections
     auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
@@ -642,6 +682,7 @@ static int upload_scene ( Scene* s ) {
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
     const size_t fn_cap = s->fast_on_device ? ntri : fnodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();      // a device build writes at most n - 1 nodes, n triangles
     size_t o_ft = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );
+    const size_t o_rp = o_td, o_lp = align ( o_rp + ref_parent.size() * 4 ); o_td = align ( o_lp + fast_leaf_parent.size() * 4 );
     std::vector<DevTexture> tdesc ( textures.size() );
     std::vector<size_t> tex_off ( textures.size() );
     size_t total = align ( o_td + tdesc.size() * sizeof ( DevTexture ) );
@@ -669,6 +710,10 @@ static int upload_scene ( Scene* s ) {
     if ( !fnodes.empty() ) {
         HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    }
+    if ( !ref_parent.empty() ) {
+        HIP_TRY ( hipMemcpy ( base + o_rp, ref_parent.data(), ref_parent.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemcpy ( base + o_lp, fast_leaf_parent.data(), fast_leaf_parent.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
     bool have_fast = !fnodes.empty();
     if ( s->fast_on_device ) {
@@ -715,6 +760,8 @@ static int upload_scene ( Scene* s ) {
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
     s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
+    s->dev.reach = ( s->reach && have_fast && !ref_parent.empty() ) ? 1u : 0u;
+    s->dev.ref_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
     s->device_ok = true;
     return 0;
@@ -859,7 +906,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.counters = s->d_counters;
     terra_plan_lds ( p );
     // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
-    const bool cam_ok = coords_within_margin ( p.cam_pos, 3 );
+    const bool cam_ok = s->reach ? ( fabsf ( p.cam_pos[0] ) <= s->reach_limit && fabsf ( p.cam_pos[1] ) <= s->reach_limit && fabsf ( p.cam_pos[2] ) <= s->reach_limit ) : coords_within_margin ( p.cam_pos, 3 );
     if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) {
         terra_plan_fast_tree ( p );
         if ( s->fast_on_device ) p.lds_nodes = 0;      // the device-built tree is not numbered top-levels-first: nothing worth staging

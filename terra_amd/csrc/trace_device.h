@@ -464,6 +464,23 @@ TD bool slab_enter ( V3 c, V3 h, const Ray& r, float& t_enter ) {
 
 struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
 
+// Would the REFERENCE traversal (src/TerraBVH.c:250-310) have tested fast triangle `ti` for this ray? It tests a leaf child whenever it visits the
+// leaf's node, and it visits a node when the slab test of that node's box -- stored in its parent -- passed, for every inner node on the way down from
+// the root. So: replay that slab test (the reference's compare-select form, unclamped inverse direction) up the parent links. Only scenes outside the
+// coordinate range of the containment proof need this (DevScene::reach): inside it, a triangle the ray hits implies all of these tests pass.
+TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
+    const float4* rn = reinterpret_cast<const float4*> ( T.sc.nodes );
+    uint32_t q = T.sc.fast_leaf_parent[ti];
+    while ( q != 0u ) {
+        const uint32_t pw = T.sc.ref_parent[q], par = pw >> 1;
+        const float4 a = rn[4 * par], b = rn[4 * par + 1], c4 = rn[4 * par + 2];
+        const V3 mn = ( pw & 1u ) ? v3 ( b.z, b.w, c4.x ) : v3 ( a.x, a.y, a.z ), mx = ( pw & 1u ) ? v3 ( c4.y, c4.z, c4.w ) : v3 ( a.w, b.x, b.y );
+        if ( !slab<false> ( mn, mx, ray ) ) return false;
+        q = par;
+    }
+    return true;
+}
+
 // Leaves are pushed on the stack like inner nodes (near child last, so it is popped first). A lane that pops a leaf
 // HOLDS it; each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and
 // some lane can still descend) the descending lanes take a node step, otherwise the holders test one triangle each.
@@ -535,7 +552,9 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             float depth;
             if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
                 uint32_t rank = __float_as_uint ( cc.w );
-                if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
+                if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) {
+                    if ( !T.sc.reach || reference_reaches ( T, ti, ray ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
+                }
             }
         }
     }

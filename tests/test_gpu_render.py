@@ -434,6 +434,45 @@ def test_fast_tree_built_on_the_device(H, L):
     L.scene_destroy(scene)
 
 
+def test_reachability_mode_outside_the_coordinate_range(H, L, monkeypatch):
+    """Coordinates beyond +-13 units: the automatic mode keeps the fast tree and accepts a hit only if the reference traversal would have reached it
+    (reference_reaches: the inner ancestors' slab tests replayed). It must equal the replica bit for bit -- also when the reference's boxes are made to miss
+    (test hook: the device copy of the reference tree shrunk), which float rounding alone does too rarely to test; the plain fast tree must then differ."""
+    import torch
+    from tools.scaled_hall import scaled
+
+    def render(mode, integ):
+        d = scaled(scenes.sponza_hall(160, 90, 2, integrator=integ), 100.0)
+        L.clear_error(); s = scenes.build_scene(L, d, tree_mode=mode)
+        assert runtime.last_error() == "", runtime.last_error()
+        ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(s, C.byref(ti)))
+        fb = runtime.DeviceFramebuffer(d.width, d.height)
+        runtime.render_device(L, scenes.camera_of(d), s, fb); torch.cuda.synchronize()
+        out = (fb.pixels_host().copy(), fb.results_host()["acc"].copy(), ti.fast_tree, ti.note.decode())
+        L.scene_destroy(s)
+        return out
+
+    for shrink in (None, "3.0"):
+        if shrink is None: monkeypatch.delenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", raising=False)
+        else: monkeypatch.setenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", shrink)
+        for integ in (0, 1):
+            ref = render(0, integ); auto = render(2, integ)
+            assert auto[2] == 1 and "reachability" in auto[3], auto[3]
+            assert same(H, ref[0], auto[0]) and same(H, ref[1], auto[1]), (shrink, integ)
+        if shrink is not None:
+            plain = render(1, 0); ref = render(0, 0)
+            assert not same(H, plain[1], ref[1])          # the hook bites: without the replay the fast tree finds hits the (shrunk) reference misses
+        # ... and ray by ray: the fast tree with the replay against the reference tree's own traversal
+        d = scaled(scenes.sponza_hall(64, 36, 1), 100.0)
+        s = scenes.build_scene(L, d, tree_mode=2)
+        o, dd = H.scene_rays(6, 4096, box=((-950.0, 30.0, -450.0), (950.0, 750.0, 450.0)))
+        U = H.Unit("amd")
+        f0, p0, pt0 = U.bvh_traverse(s, o, dd); f1, p1, pt1, _ = U.bvh_traverse_fast(s, o, dd)
+        hit = f0 != 0
+        assert np.array_equal(f0, f1) and np.array_equal(p0[hit], p1[hit]) and H.same_bits(pt0[hit], pt1[hit]) and hit.sum() > 1000, shrink
+        L.scene_destroy(s)
+
+
 def test_host_fast_tree_build_does_not_depend_on_its_threads(H, L, monkeypatch):
     """the host builder hands subtrees to several threads (tree_build.cpp); the tree -- hence the work a render does -- must be the same whatever the schedule"""
     import torch

@@ -177,10 +177,16 @@ def test_automatic_traversal_decision(H, L):
     # explicit modes are obeyed without a check
     assert _decision(L, scenes.cornell_box(32, 32, 1), 0)[:3] == (0, 0, 0)
     assert _decision(L, scenes.cornell_box(32, 32, 1), 1)[:3] == (1, 1, 0)
-    # coordinates beyond the range in which the 1e-4 box margin provably exceeds rounding error: replica traversal, with the reason
+    # coordinates beyond the range in which the 1e-4 box margin provably exceeds rounding error: never the cull; a scene that is not LDS-resident keeps the
+    # fast tree with the reference's reachability replayed per accepted hit, a resident one runs the replica -- with the reason either way
     d = soup_scene(H, 300, 9)
     for o in d.objects:
         o.triangles = (o.triangles * np.float32(40.0)).astype(np.float32)
+    mode, fast, cull, cmax, note = _decision(L, d)
+    assert (fast, cull) == (1, 0) and cmax > 13.0 and "exceeds" in note and "reachability" in note
+    d = scenes.cornell_box(32, 32, 1)
+    for o in d.objects:
+        o.triangles = (np.asarray(o.triangles, np.float32) * np.float32(40.0)).astype(np.float32)
     mode, fast, cull, cmax, note = _decision(L, d)
     assert (fast, cull) == (0, 0) and cmax > 13.0 and "exceeds" in note and "replica" in note
     # non-finite coordinates never pass
