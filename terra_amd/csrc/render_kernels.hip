@@ -209,7 +209,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
-struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, leaf; int top; bool traversing, regular; };     // top: entries on the lane's stack (its leaf list is always empty between calls)
+struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, leaf; int top; bool traversing, regular; };     // regular: MODE 0 / 1 the ray's slab variant; MODE 2 (which has no use for that) "second, checked pass" of the reachability mode     // top: entries on the lane's stack (its leaf list is always empty between calls)
 TD LaneTraversal lane_traversal_idle ( const Tracer& T, const Ray& any_ray ) {
     LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.leaf = 0; t.top = 0; t.traversing = false; t.regular = true;
     return t;
@@ -226,6 +226,18 @@ TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t
     t.traversing = true;
     if ( COUNT ) ++c.rays;
 }
+// DevScene::reach (scenes outside the coordinate range of the containment proof, MODE 2): a returned closest hit stands if the reference traversal would have
+// reached it; if not -- very rare -- the same ray goes back in flight with every candidate checked (trace_device.h bvh_traverse_fast). True = the lane is traversing again.
+template <int MODE>
+TD bool lane_traversal_recheck ( const Tracer& T, const Ray& ray, LaneTraversal& t ) {
+    if ( MODE != 2 || !T.sc.reach || !t.regular || t.best.tri == 0xffffffffu ) return false;      // (MODE 2: regular == false marks the checked pass)
+    Ray r = ray; r.o = r.o + r.d * 0.001f;
+    if ( reference_reaches ( T, t.best.tri, r ) ) return false;
+    t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.leaf = 0;
+    *T.stack = 0; t.top = 1;
+    t.traversing = true; t.regular = false;
+    return true;
+}
 // advances every traversing lane until 1 / 2^TERRA_DECOUPLED_EXIT_SHIFT of them have finished; false when no lane is traversing
 template <int COUNT, int MODE>
 TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
@@ -238,7 +250,7 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
     int* sp = T.stack + t.top * TERRA_COL;
     if constexpr ( MODE == 2 ) {
         ClosestRanked b2; b2.depth = t.best.depth; b2.rank = t.rank; b2.tri = t.best.tri;
-        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.leaf, t.traversing, exit_active, c );
+        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.leaf, t.traversing, exit_active, c, T.sc.reach && !t.regular );      // (a ray with a zero direction component starts in the checked pass: harmless)
         t.best.depth = b2.depth; t.best.tri = b2.tri; t.rank = b2.rank;
     } else {
         if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
@@ -305,7 +317,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         MisPending pend; pend.a_vis = pend.a_hid = pend.f2 = pend.p = pend.t_before = v3 ( 0, 0, 0 ); pend.expected = 0; pend.bpdf2 = pend.cos2 = 0.f; pend.light_object = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 ), b_o = v3 ( 0, 0, 0 ), b_d = v3 ( 0, 0, 1 ), lo_i = v3 ( 0, 0, 0 );
         for ( ;; ) {
-            if ( !lt.traversing && !done ) {
+            if ( !lt.traversing && !done && ! ( have_ray && lane_traversal_recheck<MODE> ( T, ray, lt ) ) ) {
                 bool start = false;
                 if ( have_ray && job != 0 ) {
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
@@ -366,7 +378,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         DirectPending pend; pend.vis = pend.hid = v3 ( 0, 0, 0 ); pend.expected = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 );
         for ( ;; ) {
-            if ( !lt.traversing && !done ) {
+            if ( !lt.traversing && !done && ! ( have_ray && lane_traversal_recheck<MODE> ( T, ray, lt ) ) ) {
                 bool start = false;
                 if ( have_ray && shadow ) {                      // the shadow ray came back
                     const uint32_t tri_s = hit_soup_index<MODE> ( T, lt.best.tri );
@@ -414,7 +426,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         LaneTraversal lt = lane_traversal_idle ( T, ray );
         bool done = !valid, have_ray = false;
         for ( ;; ) {
-            if ( !lt.traversing && !done ) {
+            if ( !lt.traversing && !done && ! ( have_ray && lane_traversal_recheck<MODE> ( T, ray, lt ) ) ) {
                 bool next = false;
                 if ( have_ray ) {
                     if ( lt.best.tri != 0xffffffffu ) {

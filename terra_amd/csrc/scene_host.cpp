@@ -609,14 +609,15 @@ static int upload_scene ( Scene* s ) {
     s->cull_ok = auto_ok;
     // Outside the range the reference's own slab test can numerically miss a box whose triangle the watertight test would hit, so the containment
     // shortcut is gone -- but not the fast tree: with its boxes inflated to the rounding bound it still finds every triangle the watertight test accepts,
-    // and a candidate is accepted only if the reference traversal would have reached it (its inner ancestors' slab tests, replayed exactly). Rays may start
+    // and a hit stands only if the reference traversal would have reached it (its inner ancestors' slab tests, replayed exactly: for the closest of all hits first, and only
+    // if that one fails -- float rounding makes it very rare -- for every candidate of a second pass; trace_device.h bvh_traverse_fast). Rays may start
     // up to TERRA_REACH_CAMERA_FACTOR x the scene's largest coordinate from the origin (the camera, checked per call); margin = 128 u x that limit.
     s->reach = false; s->reach_limit = 0.f;
     float reach_margin = 0.f;
     if ( s->tree_mode == 2 && !auto_ok && !margin_ok && ntri >= 2 && !resident && coords_finite && s->coord_max <= TERRA_REACH_MAX_COORD ) {
         s->reach = true; s->reach_limit = TERRA_REACH_CAMERA_FACTOR * s->coord_max;
         reach_margin = 128.f * 5.9604645e-8f * s->reach_limit;
-        char b[200]; snprintf ( b, sizeof b, "largest coordinate %.6g exceeds %.1f: fast tree with boxes inflated by %.3g and the reference's reachability replayed per accepted hit", ( double ) s->coord_max, ( double ) TERRA_CULL_MAX_COORD, ( double ) reach_margin );
+        char b[200]; snprintf ( b, sizeof b, "largest coordinate %.6g exceeds %.1f: fast tree with boxes inflated by %.3g, the reference's reachability replayed for the closest hit", ( double ) s->coord_max, ( double ) TERRA_CULL_MAX_COORD, ( double ) reach_margin );
         s->tree_note = b;
     }
     s->use_fast = s->tree_mode == 1 || ( auto_ok && !resident ) || s->reach;

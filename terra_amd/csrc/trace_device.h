@@ -494,7 +494,7 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 #define TERRA_FAST_LEAF_16THS 8
 #endif
 template <int COUNT>
-TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c ) {
+TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c, bool checked = false ) {
     // a ray parallel to an axis has an infinite inverse direction there, and inf - inf would drop that axis from the test:
     // correct but ruinous (such a ray then visits every box along its line; one lane walking 20k nodes alone costs tens of
     // milliseconds). Clamped to +-2^100 the axis keeps its meaning: (|c - o| - h) * 2^100 has the sign of "outside the slab".
@@ -553,7 +553,7 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
                 uint32_t rank = __float_as_uint ( cc.w );
                 if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) {
-                    if ( !T.sc.reach || reference_reaches ( T, ti, ray ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }
+                    if ( !checked || reference_reaches ( T, ti, ray ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }      // (checked: DevScene::reach, second pass)
                 }
             }
         }
@@ -563,12 +563,18 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
 
 template <int COUNT>
 TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
-    ClosestRanked best; best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-    int* top = T.stack;
-    *top = 0; top += TERRA_COL;
-    bool traversing = true; uint32_t leaf = 0;
-    traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, leaf, traversing, 0, c );
+    ClosestRanked best;
+    // DevScene::reach: the closest of ALL hits is the answer if the reference would have reached it (then it is also the closest of the reachable ones);
+    // only if not -- float rounding makes that very rare -- the ray is traced again with every candidate checked
+    for ( int pass = 0; pass < 2; ++pass ) {
+        best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
+        int* top = T.stack;
+        *top = 0; top += TERRA_COL;
+        bool traversing = true; uint32_t leaf = 0;
+        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, leaf, traversing, 0, c, pass == 1 );
+        if ( pass == 1 || !T.sc.reach || best.tri == 0xffffffffu || reference_reaches ( T, best.tri, r ) ) break;
+    }
     return best;
 }
 
