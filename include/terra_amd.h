@@ -65,8 +65,10 @@ uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
    2 = automatic (DEFAULT): at commit the scene is checked numerically (every coordinate within +-13 units, where the reference's
        1e-4 box margin provably exceeds the rounding error of the slab and triangle tests; every leaf / fast-tree box contains what
        it was built around). Scenes that pass run the reference tree with the leaf-box cull (a leaf's triangle is tested only
-       if the ray passes that leaf's own box) when they fit in LDS, and the fast tree otherwise; scenes that fail -- and calls
-       whose camera lies outside the checked range -- run as mode 0. All three produce the reference's image bit for bit; only
+       if the ray passes that leaf's own box) when they fit in LDS, and the fast tree otherwise. Scenes beyond that range that do not fit
+       in LDS keep the fast tree with its boxes inflated to the rounding bound, and a closest hit stands only if the reference traversal
+       would have reached it (the slab tests of its ancestors in the reference tree are replayed; DESIGN.md "Reachability mode"); the rest --
+       and calls whose camera lies outside the checked range -- run as mode 0. All produce the reference's image bit for bit; only
        mode 0 also reproduces its work counters. terra_amd_traversal_info() reports the decision and the reason.
    Takes effect at the next terra_scene_commit(). */
 int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
