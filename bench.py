@@ -131,6 +131,14 @@ def workload(name: str, spp_override=0):
         d = scenes.sponza_hall(1920, 1080, 256, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "hall_2160p_4096spp":       # BASELINE.json configs[4]: the 100k scene at 3840x2160, 4096 spp (meant for 8 GPUs)
         d = scenes.sponza_hall(3840, 2160, 4096, bounces=8, integrator=api.kTerraIntegratorSimple)
+    elif name == "hall_x100_1080p_64spp":    # the hall with every coordinate (scene and camera) x 100: outside the +-13-unit range of the containment proof, the
+        # automatic mode keeps the fast tree and replays the reference's reachability for the closest hit
+        import numpy as np
+        d = scenes.sponza_hall(1920, 1080, 64, bounces=8, integrator=api.kTerraIntegratorSimple)
+        for o in d.objects:
+            o.triangles = (np.asarray(o.triangles, np.float32) * np.float32(100.0)).astype(np.float32)
+        d.camera_position = tuple(float(np.float32(c) * np.float32(100.0)) for c in d.camera_position)
+        d.name = "sponza_hall_x100"
     elif name == "spheres_1080p_1024spp":    # BASELINE.json configs[3]: glass + GGX spheres (this repo's presets; no reference behaviour)
         d = scenes.cornell_spheres(1920, 1080, 1024, bounces=8, integrator=api.kTerraIntegratorSimple)
     else:
@@ -425,7 +433,7 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
 def result_block(d, name, tree, split, steps, warmup, world, m, spp_override, integrator_name):
     frame_samples = d.width * d.height * d.spp
     st = m["per_launch"] or {}
-    trav = "fast tree" if m["traversal"]["fast_tree"] else ("reference tree + leaf-box cull" if m["traversal"]["leaf_cull"] else "reference tree, replica traversal")
+    trav = ("fast tree + reachability replay" if "reachability" in m["traversal"]["note"] else "fast tree") if m["traversal"]["fast_tree"] else ("reference tree + leaf-box cull" if m["traversal"]["leaf_cull"] else "reference tree, replica traversal")
     out = {"value": round(frame_samples * steps / m["elapsed"] / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(m["elapsed"] / steps * 1e3, 3),
            "config": {"workload": name, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces, "integrator": integrator_name,
@@ -442,6 +450,7 @@ EXTRA_WORKLOADS = [
     # (workload, tree, integrator, split, steps, warmup, prewarm rectangle, CPU seconds)
     ("hall_1080p_256spp", "auto", "simple", 1, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
     ("hall_1080p_256spp", "reference", "simple", 1, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (6 s per step)
+    ("hall_x100_1080p_64spp", "auto", "simple", 1, 2, 1, None, 6.0),                   # the hall outside the coordinate range: fast tree + reachability replay
     ("spheres_1080p_1024spp", "auto", "simple", 8, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
     ("cornell_1080p_512spp_direct", "auto", "direct", 8, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
 ]
