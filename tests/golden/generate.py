@@ -20,6 +20,7 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE.parent.parent))
 import harness as H  # noqa: E402
 from terra_amd import api, scenes  # noqa: E402
 
@@ -129,6 +130,15 @@ def main():
     hall["trav_found"] = found; hall["trav_prim"] = prim; hall["trav_point"] = point
     L.scene_destroy(sc)
     manifest["files"]["render_hall"] = save("render_hall", **hall)
+
+    # the same hall with every coordinate (scene and camera) x 100: outside the +-13-unit range in which the 1e-4 box margins provably exceed rounding error;
+    # the product's automatic mode renders it with the fast tree and the reference's reachability replayed -- this is what it has to reproduce
+    from tools.scaled_hall import scaled
+    hall100 = {}
+    for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
+        o5 = ref.render_pixels(scaled(scenes.sponza_hall(w, h, spp, integrator=integ), 100.0))
+        hall100[f"i{integ}_pixels"] = o5["pixels"]; hall100[f"i{integ}_calls"] = o5["rand_calls"].astype(np.uint16)
+    manifest["files"]["render_hall_x100"] = save("render_hall_x100", **hall100)
 
     # textured attributes (byte/float textures, point/bilinear, wrap/clamp, textured emissive)
     tex = {}

@@ -452,6 +452,12 @@ def test_reachability_mode_outside_the_coordinate_range(H, L, monkeypatch):
         L.scene_destroy(s)
         return out
 
+    # the compiled reference's own image of the scaled hall (tests/golden/render_hall_x100.npz)
+    monkeypatch.delenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", raising=False)
+    g = G(H, "render_hall_x100")
+    for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
+        out = render_dev(L, scaled(scenes.sponza_hall(w, h, spp, integrator=integ), 100.0), calls=True)
+        assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]) and np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32)), integ
     for shrink in (None, "3.0"):
         if shrink is None: monkeypatch.delenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", raising=False)
         else: monkeypatch.setenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", shrink)

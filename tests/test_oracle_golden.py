@@ -3,6 +3,8 @@ tests/golden/generate.py dumped from the compiled reference, bit for bit.
 This is what pins the oracle (task section 3): it runs without /root/reference."""
 import json
 
+import sys
+
 import numpy as np
 import pytest
 
@@ -140,6 +142,17 @@ def test_hall_100k(H, orc_lib):
     u.L.scene_destroy(sc)
     for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
         out = u.render_pixels(scenes.sponza_hall(w, h, spp, integrator=integ))
+        assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]) and np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32))
+
+
+def test_hall_x100_outside_the_coordinate_range(H, orc_lib):
+    """the hall with every coordinate x 100 (the 1e-4 box margins no longer exceed rounding error there): the oracle against the compiled reference"""
+    sys.path.insert(0, str(H.ROOT))
+    from tools.scaled_hall import scaled
+    g = G(H, "render_hall_x100")
+    u = H.Unit("orc")
+    for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
+        out = u.render_pixels(scaled(scenes.sponza_hall(w, h, spp, integrator=integ), 100.0))
         assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]) and np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32))
 
 

@@ -1,11 +1,10 @@
 """The hall with every coordinate (scene and camera) multiplied by a factor: outside the +-13-unit range of the containment proof the automatic mode
 runs the fast tree with the reference's reachability replayed (DESIGN.md "Reachability"). Compares it with the replica traversal and times both.
     python tools/scaled_hall.py [--scale 100] [--spp 8] [--integrator 0]"""
-import torch  # first: libterra_amd.so must bind to the HIP runtime torch loaded
 import argparse, ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from terra_amd import runtime, scenes
+from terra_amd import scenes
 
 
 def scaled(d, k):
@@ -16,9 +15,11 @@ def scaled(d, k):
 
 
 if __name__ == "__main__":
+    import torch  # before the library: libterra_amd.so must bind to the HIP runtime torch loaded
     ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=float, default=100.0); ap.add_argument("--spp", type=int, default=8); ap.add_argument("--integrator", type=int, default=0)
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
     a = ap.parse_args()
+    from terra_amd import runtime
     L = runtime.load()
     outs = {}
     for mode in (2, 0):
