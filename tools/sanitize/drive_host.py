@@ -12,6 +12,10 @@ def soup(n):
 cases = [scenes.cornell_box(8,8,1), scenes.cornell_textured(8,8,1), scenes.cornell_spheres(8,8,1), scenes.sponza_hall(8,8,1)]
 for n in (0,1,2,3,5,17,300,4000):
     cases.append(scenes.SceneDesc(objects=soup(n) if n else [], width=8, height=8, spp=1))
+def big(d, k):          # every coordinate x k: beyond +-13 units the automatic mode takes the reachability path (inflated boxes, parent links)
+    for o in d.objects: o.triangles = (np.asarray(o.triangles, np.float32) * np.float32(k)).astype(np.float32)
+    return d
+cases += [big(scenes.sponza_hall(8,8,1), 100.0), big(scenes.SceneDesc(objects=soup(600), width=8, height=8, spp=1), 1000.0)]
 for d in cases:
     for tm in (0,1,2):
         s = lib.scene_create(); settree(s, tm)
