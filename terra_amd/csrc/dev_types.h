@@ -108,6 +108,10 @@ struct DevScene {
     // fast_leaf_parent[i] = the reference node whose leaf child fast triangle i is
     const uint32_t*    ref_parent;
     const uint32_t*    fast_leaf_parent;
+    // fast_leaf_mask[i]: bit L set = the box of the L-th node on the way up from fast triangle i's leaf (L = 0: the leaf's node, as its parent stores it) does NOT contain
+    // the triangle's extent with a clearance above the rounding bound, so its slab test has to be replayed; a clear bit = that test cannot fail for a ray that hits the
+    // triangle (the containment argument, at the scene's scale). Bit 31 stands for every level from 31 up.
+    const uint32_t*    fast_leaf_mask;
     uint32_t           reach;
     // environment lighting (terra_amd_set_environment_lighting; off = the reference's behaviour):
     // 0 off, 1 constant env_color, 2 lat-long lookup of textures[env_tex] by ray direction

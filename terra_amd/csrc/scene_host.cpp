@@ -589,7 +589,7 @@ static int upload_scene ( Scene* s ) {
         }
     }
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
-    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device, ref_parent, fast_leaf_parent;
+    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device, ref_parent, fast_leaf_parent, fast_leaf_mask;
     s->fast_nodes = 0; s->fast_max_stack = 1; s->fast_on_device = false;
     // traversal policy (see Scene::tree_mode and the containment check above)
     s->coord_max = 0.f; s->cull_ok = false; s->tree_note.clear();
@@ -668,8 +668,25 @@ static int upload_scene ( Scene* s ) {
                     if ( w == DEV_CHILD_EMPTY ) continue;
                     if ( w & DEV_CHILD_LEAF ) leaf_parent[w & 0x7fffffffu] = ( uint32_t ) k; else ref_parent[w] = ( uint32_t ) ( k << 1 ) | ( uint32_t ) c;
                 }
-                fast_leaf_parent.resize ( ntri );
-                for ( size_t k = 0; k < built.order.size(); ++k ) fast_leaf_parent[k] = leaf_parent[built.order[k]];
+                fast_leaf_parent.resize ( ntri ); fast_leaf_mask.resize ( ntri );
+                for ( size_t k = 0; k < built.order.size(); ++k ) {
+                    const uint32_t soup = built.order[k];
+                    fast_leaf_parent[k] = leaf_parent[soup];
+                    // which ancestors' slab tests can fail at all for a ray that hits this triangle: those whose box does not clear the triangle's extent by the margin
+                    // (the boxes as the DEVICE holds them: what the replay tests)
+                    float lo[3], hi[3];
+                    for ( int a = 0; a < 3; ++a ) { lo[a] = std::min ( tris[soup].a[a], std::min ( tris[soup].b[a], tris[soup].c[a] ) ); hi[a] = std::max ( tris[soup].a[a], std::max ( tris[soup].b[a], tris[soup].c[a] ) ); }
+                    uint32_t mask = 0, level = 0;
+                    for ( uint32_t q = leaf_parent[soup]; q != 0u; ++level ) {
+                        const uint32_t pw = ref_parent[q], par = pw >> 1;
+                        const float* mn = ( pw & 1u ) ? nodes[par].min1 : nodes[par].min0; const float* mx = ( pw & 1u ) ? nodes[par].max1 : nodes[par].max0;
+                        bool clear = true;
+                        for ( int a = 0; a < 3; ++a ) clear = clear && ( lo[a] - mn[a] >= reach_margin ) && ( mx[a] - hi[a] >= reach_margin );      // (false for NaN)
+                        if ( !clear ) mask |= 1u << ( level < 31u ? level : 31u );
+                        q = par;
+                    }
+                    fast_leaf_mask[k] = mask;
+                }
             }
             s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
         }
@@ -683,7 +700,7 @@ static int upload_scene ( Scene* s ) {
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
     const size_t fn_cap = s->fast_on_device ? ntri : fnodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();      // a device build writes at most n - 1 nodes, n triangles
     size_t o_ft = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );
-    const size_t o_rp = o_td, o_lp = align ( o_rp + ref_parent.size() * 4 ); o_td = align ( o_lp + fast_leaf_parent.size() * 4 );
+    const size_t o_rp = o_td, o_lp = align ( o_rp + ref_parent.size() * 4 ), o_lm = align ( o_lp + fast_leaf_parent.size() * 4 ); o_td = align ( o_lm + fast_leaf_mask.size() * 4 );
     std::vector<DevTexture> tdesc ( textures.size() );
     std::vector<size_t> tex_off ( textures.size() );
     size_t total = align ( o_td + tdesc.size() * sizeof ( DevTexture ) );
@@ -715,6 +732,7 @@ static int upload_scene ( Scene* s ) {
     if ( !ref_parent.empty() ) {
         HIP_TRY ( hipMemcpy ( base + o_rp, ref_parent.data(), ref_parent.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_lp, fast_leaf_parent.data(), fast_leaf_parent.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemcpy ( base + o_lm, fast_leaf_mask.data(), fast_leaf_mask.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
     bool have_fast = !fnodes.empty();
     if ( s->fast_on_device ) {
@@ -762,7 +780,7 @@ static int upload_scene ( Scene* s ) {
     s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
     s->dev.reach = ( s->reach && have_fast && !ref_parent.empty() ) ? 1u : 0u;
-    s->dev.ref_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr;
+    s->dev.ref_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
     s->device_ok = true;
     return 0;

@@ -468,17 +468,28 @@ struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
 // leaf's node, and it visits a node when the slab test of that node's box -- stored in its parent -- passed, for every inner node on the way down from
 // the root. So: replay that slab test (the reference's compare-select form, unclamped inverse direction) up the parent links. Only scenes outside the
 // coordinate range of the containment proof need this (DevScene::reach): inside it, a triangle the ray hits implies all of these tests pass.
+#ifndef TERRA_REACH_SELFCHECK      // check builds: replay every level and count (terra_amd_debug_faults) the ones the mask had cleared that fail -- must stay 0
+#define TERRA_REACH_SELFCHECK 0
+#endif
 TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
     const float4* rn = reinterpret_cast<const float4*> ( T.sc.nodes );
+    uint32_t mask = T.sc.fast_leaf_mask[ti];                 // levels whose test can fail at all (DevScene::fast_leaf_mask); the walk ends above the highest of them
     uint32_t q = T.sc.fast_leaf_parent[ti];
-    while ( q != 0u ) {
+    bool ok = true;
+    while ( q != 0u && ( TERRA_REACH_SELFCHECK || mask != 0u ) ) {
         const uint32_t pw = T.sc.ref_parent[q], par = pw >> 1;
-        const float4 a = rn[4 * par], b = rn[4 * par + 1], c4 = rn[4 * par + 2];
-        const V3 mn = ( pw & 1u ) ? v3 ( b.z, b.w, c4.x ) : v3 ( a.x, a.y, a.z ), mx = ( pw & 1u ) ? v3 ( c4.y, c4.z, c4.w ) : v3 ( a.w, b.x, b.y );
-        if ( !slab<false> ( mn, mx, ray ) ) return false;
+        if ( TERRA_REACH_SELFCHECK || ( mask & 1u ) ) {
+            const float4 a = rn[4 * par], b = rn[4 * par + 1], c4 = rn[4 * par + 2];
+            const V3 mn = ( pw & 1u ) ? v3 ( b.z, b.w, c4.x ) : v3 ( a.x, a.y, a.z ), mx = ( pw & 1u ) ? v3 ( c4.y, c4.z, c4.w ) : v3 ( a.w, b.x, b.y );
+            if ( !slab<false> ( mn, mx, ray ) ) {
+                if ( !TERRA_REACH_SELFCHECK ) return false;
+                if ( mask & 1u ) ok = false; else if ( T.faults ) atomicAdd ( T.faults, 1ull );      // a cleared level failed: the mask is wrong
+            }
+        }
         q = par;
+        mask = ( mask & 0x80000000u ) | ( mask >> 1 );      // next level (bit 31 stands for every level from 31 up)
     }
-    return true;
+    return ok;
 }
 
 // Leaves are pushed on the stack like inner nodes (near child last, so it is popped first). A lane that pops a leaf

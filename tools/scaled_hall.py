@@ -31,8 +31,9 @@ if __name__ == "__main__":
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); runtime.render_device(L, cam, s, fb); e1.record(); torch.cuda.synchronize()
         st = runtime.Stats(); runtime.check(L.get_stats(s, C.byref(st))); st = st.as_dict()
+        faults = L.fn("terra_amd_debug_faults", C.c_longlong, [C.c_void_p])(s)          # (self-checking builds: levels the replay mask had cleared that failed)
         ms = e0.elapsed_time(e1)
-        print(f"scale {a.scale:g} tree mode {mode}: {ms:9.2f} ms  {d.width * d.height * a.spp / ms / 1e3:8.1f} Msamples/s  nodes/ray {st['nodes'] / max(1, st['rays']) / 2:.1f}  fast {ti.fast_tree}  note: {ti.note.decode()}", flush=True)
+        print(f"scale {a.scale:g} tree mode {mode}: {ms:9.2f} ms  {d.width * d.height * a.spp / ms / 1e3:8.1f} Msamples/s  nodes/ray {st['nodes'] / max(1, st['rays']) / 2:.1f}  fast {ti.fast_tree}  check-build faults {faults}  note: {ti.note.decode()}", flush=True)
         outs[mode] = (fb.pixels_host().copy(), fb.results_host()["acc"].copy())
         L.scene_destroy(s)
     same = np.array_equal(outs[2][0].view(np.uint32), outs[0][0].view(np.uint32)) and np.array_equal(outs[2][1].view(np.uint32), outs[0][1].view(np.uint32))
