@@ -14,7 +14,9 @@
  * remove_vertex_duplicates, flip_z, flip_faces_winding_order. Apollo.h does not compile with this image's toolchains, so its
  * policy is RESTATED here and pinned by hand-derived fixtures (tests/test_headless_tool.py), not by running it:
  *   - one object per `g` / `o` group (a group is opened implicitly by the first `usemtl`, `s` or `f`); the group's material is
- *     the LAST `usemtl` inside it; `illum specular` (Apollo's own MTL dialect) or a non-zero Ks selects Phong;
+ *     the LAST `usemtl` inside it; the material's class is the word of Apollo's own `illum <word>` dialect (Apollo.h:877-897) and only
+ *     `illum specular` selects Phong: diffuse, mirror, pbr, disney and materials without such a word (every standard MTL file, whose
+ *     `illum 2` Apollo rejects) become diffuse, the last four with a warning, as satellite/src/Scene.cpp:193-230 does; Ke is the emissive;
  *   - z is negated at parse time and every triangle (a, b, c) becomes (c, b, a);
  *   - the file's `vn` are ignored. Face normal = normalize(cross(v1 - v0, v2 - v0)) of the flipped triangle. A group is smooth
  *     iff its last `s` token starts with '1'; in smooth groups corners with bit-equal positions share one vertex (the first one
@@ -22,8 +24,8 @@
  *     normals of the triangles the vertex was PARSED for: corners 0-2 of a polygon count for its first triangle only, corner
  *     j >= 3 for triangle j - 2 (Apollo records adjacency per parsed corner, Apollo.h:1373-1381); `s off` / `s 0` groups get
  *     the face normal per triangle; groups without any `s` take the smooth path without sharing, i.e. face normals again.
- * --normals file keeps the file's `vn` (area-weighted smooth normals per position where absent) and one object per material:
- * this repo's own policy, not the reference's.
+ * --normals file keeps the file's `vn` (area-weighted smooth normals per position where absent), one object per material, and reads
+ * standard MTL files the usual way (Ks > 0 -> Phong when there is no Apollo `illum` word): this repo's own policy, not the reference's.
  *
  *   terra_headless scene.obj out.png [--width W] [--height H] [--spp N] [--bounces N]
  *       [--integrator simple|direct|mis|normals|depth] [--tonemap none|linear|reinhard|filmic|uncharted2]
@@ -47,7 +49,11 @@ void        terra_amd_set_frame_seed ( HTerraScene, uint64_t ) __attribute__ ( (
 #define VEC(T) struct { T* d; size_t n, cap; }
 #define PUSH(v, x) do { if ( ( v ).n == ( v ).cap ) { ( v ).cap = ( v ).cap ? ( v ).cap * 2 : 256; ( v ).d = realloc ( ( v ).d, ( v ).cap * sizeof *( v ).d ); } ( v ).d[( v ).n++] = ( x ); } while ( 0 )
 
-typedef struct { char name[128]; float kd[3], ks[3], ke[3], ns; int illum_specular; } Mtl;     /* illum_specular: 1 / 0 from Apollo's `illum specular|diffuse`, -1 unset */
+/* illum: Apollo's BSDF class of the material (satellite/include/Apollo.h:80-87, set ONLY by its own `illum <word>` dialect, :877-897):
+   0 diffuse, 1 specular, 2 mirror, 3 pbr, 4 disney, 5 invalid = no `illum` line or a word Apollo does not know (the numeric models of
+   standard MTL files included: "Unsupported material bsdf", the class stays invalid) */
+enum { ILLUM_DIFFUSE = 0, ILLUM_SPECULAR, ILLUM_MIRROR, ILLUM_PBR, ILLUM_DISNEY, ILLUM_INVALID };
+typedef struct { char name[128]; float kd[3], ks[3], ke[3], ns; int illum; } Mtl;
 typedef struct { int v[3], t[3], n[3]; int mtl; } Face;
 typedef struct { int v, t, n; } Corner;
 typedef struct { size_t first, count; int group; } Poly;              /* corners [first, first + count) in file order */
@@ -81,14 +87,18 @@ static void load_mtl ( Model* m, const char* dir, const char* file ) {
         if ( strcmp ( key, "newmtl" ) == 0 ) {
             Mtl x; memset ( &x, 0, sizeof x );
             sscanf ( rest, "%127s", x.name );
-            x.kd[0] = x.kd[1] = x.kd[2] = 0.7f; x.ns = 1.f; x.illum_specular = -1;
+            x.kd[0] = x.kd[1] = x.kd[2] = 0.7f; x.ns = 1.f; x.illum = ILLUM_INVALID;
             PUSH ( m->mtls, x ); cur = &m->mtls.d[m->mtls.n - 1];
         } else if ( cur ) {
             if ( strcmp ( key, "Kd" ) == 0 ) sscanf ( rest, "%f %f %f", &cur->kd[0], &cur->kd[1], &cur->kd[2] );
             else if ( strcmp ( key, "Ks" ) == 0 ) sscanf ( rest, "%f %f %f", &cur->ks[0], &cur->ks[1], &cur->ks[2] );
             else if ( strcmp ( key, "Ke" ) == 0 ) sscanf ( rest, "%f %f %f", &cur->ke[0], &cur->ke[1], &cur->ke[2] );
             else if ( strcmp ( key, "Ns" ) == 0 ) sscanf ( rest, "%f", &cur->ns );
-            else if ( strcmp ( key, "illum" ) == 0 ) { char v[64] = ""; sscanf ( rest, "%63s", v ); if ( !strcmp ( v, "specular" ) ) cur->illum_specular = 1; else if ( !strcmp ( v, "diffuse" ) ) cur->illum_specular = 0; }
+            else if ( strcmp ( key, "illum" ) == 0 ) {
+                static const char* words[] = { "diffuse", "specular", "mirror", "pbr", "disney" };
+                char v[64] = ""; sscanf ( rest, "%63s", v );
+                for ( int k = 0; k < 5; ++k ) if ( !strcmp ( v, words[k] ) ) cur->illum = k;      /* any other word leaves the class as it was (Apollo.h:895-897) */
+            }
         }
     }
     fclose ( f );
@@ -145,7 +155,7 @@ static int load_obj ( Model* m, const char* path ) {
 /* ---- scene construction ---------------------------------------------------------------------- */
 static TerraFloat3 flipz ( TerraFloat3 v, int flip ) { if ( flip ) v.z = -v.z; return v; }
 
-static void set_material ( TerraObject* o, const Mtl* mt );
+static void set_material ( TerraObject* o, const Mtl* mt, int apollo );
 static void dump_object ( FILE* f, size_t j, const TerraObject* o );
 
 static HTerraScene build_scene ( Model* m, int flip, FILE* dump ) {
@@ -186,8 +196,8 @@ static HTerraScene build_scene ( Model* m, int flip, FILE* dump ) {
             o->properties[k].texcoord_a = T[0]; o->properties[k].texcoord_b = T[1]; o->properties[k].texcoord_c = T[2];
             ++k;
         }
-        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f; def.illum_specular = -1;
-        set_material ( o, want >= 0 ? &m->mtls.d[want] : &def );
+        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f; def.illum = ILLUM_INVALID;
+        set_material ( o, want >= 0 ? &m->mtls.d[want] : &def, 0 );
         if ( dump ) dump_object ( dump, terra_scene_count_objects ( scene ) - 1, o );
     }
     free ( smooth );
@@ -199,11 +209,19 @@ typedef struct { TerraFloat3 pos; TerraFloat2 tex; TerraFloat3 norm; VEC ( unsig
 typedef struct { unsigned bits[3]; unsigned value; int used; } VSlot;
 static unsigned pos_hash ( const unsigned* b ) { unsigned h = 2166136261u; for ( int i = 0; i < 3; ++i ) { h ^= b[i]; h *= 16777619u; h ^= h >> 13; } return h; }
 
-static void set_material ( TerraObject* o, const Mtl* mt ) {
+/* Material class -> preset. apollo = 1: the reference client's switch (satellite/src/Scene.cpp:193-230): APOLLO_SPECULAR -> Phong; mirror, pbr and
+   everything else (disney, and the invalid class of a material without an Apollo `illum` word) fall through its warnings to diffuse.
+   apollo = 0 (--normals file, this repo's policy for standard MTL files): `illum specular`, or no Apollo word and Ks > 0, -> Phong. */
+static void set_material ( TerraObject* o, const Mtl* mt, int apollo ) {
     TerraFloat3 kd = terra_f3_setv ( mt->kd ), ks = terra_f3_setv ( mt->ks ), ke = terra_f3_setv ( mt->ke ), zero = terra_f3_zero;
     o->material.ior = 1.5f;                                /* Scene.cpp:187 */
     terra_attribute_init_constant ( &o->material.emissive, &ke );
-    const int phong = mt->illum_specular >= 0 ? mt->illum_specular : ( ks.x + ks.y + ks.z > 0.f );
+    int phong = mt->illum == ILLUM_SPECULAR;
+    if ( !apollo && mt->illum == ILLUM_INVALID ) phong = ks.x + ks.y + ks.z > 0.f;
+    if ( apollo && mt->illum != ILLUM_SPECULAR && mt->illum != ILLUM_DIFFUSE ) {      /* the reference warns and goes on (Scene.cpp:215-220) */
+        static const char* what[] = { "", "", "mirror", "pbr", "disney", "unclassified (no Apollo `illum` word)" };
+        fprintf ( stderr, "terra_headless: unsupported %s material(%s). Defaulting to diffuse\n", what[mt->illum], mt->name[0] ? mt->name : "<none>" );
+    }
     if ( phong ) {                                         /* specular -> Phong (Scene.cpp:193-213) */
         TerraFloat3 ns = terra_f3_set1 ( mt->ns );
         terra_attribute_init_constant ( &o->material.attributes[TERRA_PHONG_ALBEDO], &kd );
@@ -304,8 +322,8 @@ static HTerraScene build_scene_apollo ( Model* m, int flip, FILE* dump ) {
             o->properties[k].texcoord_a = a->tex; o->properties[k].texcoord_b = b->tex; o->properties[k].texcoord_c = c->tex;
             ++k;
         }
-        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f; def.illum_specular = -1;
-        set_material ( o, m->groups.d[g].mtl >= 0 ? &m->mtls.d[m->groups.d[g].mtl] : &def );
+        Mtl def; memset ( &def, 0, sizeof def ); def.kd[0] = def.kd[1] = def.kd[2] = 0.7f; def.ns = 1.f; def.illum = ILLUM_INVALID;
+        set_material ( o, m->groups.d[g].mtl >= 0 ? &m->mtls.d[m->groups.d[g].mtl] : &def, 1 );
         if ( dump ) dump_object ( dump, terra_scene_count_objects ( scene ) - 1, o );
     }
     for ( size_t i = 0; i < verts.n; ++i ) free ( verts.d[i].adj.d );
@@ -316,6 +334,12 @@ static HTerraScene build_scene_apollo ( Model* m, int flip, FILE* dump ) {
 /* --dump-scene: every object exactly as it was filled through terra_scene_add_object (text, %.9g round-trips a float): for the loader's tests */
 static void dump_object ( FILE* f, size_t j, const TerraObject* o ) {
     fprintf ( f, "object %zu triangles %zu attributes %zu\n", j, o->triangles_count, o->material.attributes_count );
+    {   /* the material as it was filled: preset (by its attribute count), constant attribute values in slot order, emissive, ior */
+        const TerraMaterial* mt = &o->material;
+        fprintf ( f, "m %s", mt->attributes_count == TERRA_PHONG_END ? "phong" : "diffuse" );
+        for ( size_t a = 0; a < mt->attributes_count; ++a ) fprintf ( f, " %.9g %.9g %.9g", mt->attributes[a].value.x, mt->attributes[a].value.y, mt->attributes[a].value.z );
+        fprintf ( f, " e %.9g %.9g %.9g ior %.9g\n", mt->emissive.value.x, mt->emissive.value.y, mt->emissive.value.z, mt->ior );
+    }
     for ( size_t i = 0; i < o->triangles_count; ++i ) {
         const TerraTriangle* t = &o->triangles[i]; const TerraTriangleProperties* q = &o->properties[i];
         fprintf ( f, "t %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g n %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g uv %.9g %.9g %.9g %.9g %.9g %.9g\n",
@@ -404,7 +428,17 @@ static int write_image ( const char* path, const TerraFramebuffer* fb ) {
 /* ---- main ------------------------------------------------------------------------------------ */
 static int pick ( const char* v, const char* const* names, int n, int dflt ) { for ( int i = 0; i < n; ++i ) if ( strcmp ( v, names[i] ) == 0 ) return i; return dflt; }
 
+static const char* kHelp =
+    "usage: terra_headless scene.obj out.{png,ppm,pfm,hdr} [options]\n"
+    "  --width W --height H --spp N --bounces N --integrator simple|direct|mis|normals|depth --tonemap none|linear|reinhard|filmic|uncharted2\n"
+    "  --camera px py pz dx dy dz --fov deg --exposure e --gamma g --jitter j --no-flip-z --normals apollo|file\n"
+    "  --dump-scene file --no-render --fast-tree | --replica-tree --sample-split n --seed n --tile n\n"
+    "OBJ/MTL import (--normals apollo, the default): the policy of the reference client's importer (satellite/include/Apollo.h under the\n"
+    "options of satellite/src/Scene.cpp:83-93) RESTATED in this tool and pinned by hand-derived fixtures -- restated, not executed: Apollo.h\n"
+    "does not compile with this image's toolchains. Everything after the TerraObject fill (commit, render, export) is the pinned path.\n";
+
 int main ( int argc, char** argv ) {
+    for ( int i = 1; i < argc; ++i ) if ( !strcmp ( argv[i], "--help" ) || !strcmp ( argv[i], "-h" ) ) { fputs ( kHelp, stdout ); return 0; }
     if ( argc < 3 ) { fprintf ( stderr, "usage: terra_headless scene.obj out.{png,ppm,pfm,hdr} [options]\n" ); return 64; }
     size_t W = 800, H = 600, spp = 8, bounces = 4, tile = 0;     /* defaults of satellite/include/Config.hpp:19-113 */
     int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = -1, have_seed = 0, split = -1, apollo = 1;

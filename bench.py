@@ -32,6 +32,10 @@ Also on the JSON line (rank 0):
   cpu_baseline -- the reference's own CPU renderer (oracle/_ref, prebuilt from its unmodified sources; kind "reference")
                   on all usable host cores over a bounded sample of the same workload, with the oracle's rate beside it
                   (port_value); the oracle alone (kind "port") when the prebuilt reference library is absent. N=1 only.
+  host_api     -- (N=1) the same frame through the drop-in boundary, terra_render() on a host framebuffer, PCIe included: one
+                  full-frame call per step, and the reference client's 128-pixel tile loop from 8 threads. Never `value`.
+  phases       -- (N>1) per rank: render / pack / gather / unpack milliseconds per step (HIP events on the two streams), the
+                  slowest rank, and sharded_equals_unsharded (one extra low-spp step, checked bit for bit on rank 0)
   workloads    -- (N=1, default invocation) the other BASELINE.json configurations measured the same way in the same run,
                   each with its own value / ms_per_step / roofline / cpu_baseline. The headline stays configs[1].
 """
@@ -65,11 +69,14 @@ def parse_args(argv=None):
     ap.add_argument("--integrator", default="", choices=["", "simple", "direct", "mis"], help="override the workload's integrator (the result is then NOT the headline config)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the `host_api` block (the same frame through terra_render() on a host framebuffer)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other configurations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
     ap.add_argument("--tree", default="auto", choices=list(TREE_MODES), help="terra_amd_set_tree_mode: auto (2, the library default: leaf-box cull / fast tree when the scene passes the numeric containment check), reference (0: the reference's tree, every traversal decision reproduced), fast (1)")
     ap.add_argument("--sample-split", type=int, default=8, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
-    ap.add_argument("--check", action="store_true", help="after timing: one sharded+gathered pass on a cleared frame must equal an unsharded pass bit for bit (rank 0)")
+    ap.add_argument("--check", action="store_true", help="after timing: one low-spp sharded+gathered pass into a fresh frame must equal an unsharded pass bit for bit (rank 0); on by default when N > 1")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip that extra pass")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-started N-rank child may run before it is killed (a hung rendezvous must not hang the parent)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0 = pick a free one)")
     return ap.parse_args(argv)
 
@@ -91,16 +98,28 @@ def free_port():
 
 
 def self_launch(args, argv) -> int:
-    """bench.py --gpus N (N > 1) without a launcher: run the N ranks as a child torch.distributed.run, relay rank 0's JSON line"""
+    """bench.py --gpus N (N > 1) without a launcher: run the N ranks as a child torch.distributed.run (its own process group, so a hung
+    rendezvous can be killed whole after --launch-timeout), pass the ranks' stderr through live, relay rank 0's JSON line"""
+    import signal
     port = args.master_port or free_port()
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.run(launcher_command(args, argv, port), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p = subprocess.Popen(launcher_command(args, argv, port), env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+    try:
+        stdout, _ = p.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)            # the exact group this call started
+        except ProcessLookupError:
+            pass
+        stdout, _ = p.communicate()
+        sys.stderr.write((stdout or "")[-4000:] + f"\nbench.py: the {args.gpus}-rank child did not finish within {args.launch_timeout:.0f} s and was killed\n")
+        return 124
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in (stdout or "").splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
     if p.returncode != 0 or line is None:
-        sys.stderr.write(p.stdout[-4000:] + "\n" + p.stderr[-6000:] + "\n")
+        sys.stderr.write((stdout or "")[-4000:] + "\n")
         sys.stderr.write(f"bench.py: the {args.gpus}-rank child exited with code {p.returncode}" + ("" if line else " and printed no result line") + "\n")
         return p.returncode or 1
     print(line, flush=True)
@@ -343,8 +362,8 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     ti = runtime.TraversalInfo(); runtime.check(lib.traversal_info(scene, C.byref(ti)))
     info = runtime.SceneInfo(); runtime.check(lib.scene_info(scene, C.byref(info)))
     cam = scenes.camera_of(d)
-    fb = runtime.DeviceFramebuffer(d.width, d.height, device=dev)
     W, H = d.width, d.height
+    cur = {"scene": scene, "fb": runtime.DeviceFramebuffer(W, H, device=dev)}      # what step() renders into (the check pass swaps both)
     main = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev) if c.dist_on else None
     n_packed = runtime.packed_floats_per_rank(W, H, TILE, world)
@@ -352,14 +371,19 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     pool = [torch.zeros(n_packed, dtype=torch.float32, device="cpu" if c.via_host else dev) for _ in range(world)] if (c.dist_on and rank == 0) else []
     stage = torch.zeros(n_packed, dtype=torch.float32, device=dev) if (c.via_host and rank == 0) else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    PH = ("side_start", "packed", "gathered", "unpacked")
+    pev = [{k: torch.cuda.Event(enable_timing=True) for k in PH} for _ in range(steps)] if c.dist_on else []      # phase marks on the side stream
+    host_ph = [dict() for _ in range(steps)]                                                                      # ... and on the host clock (the gloo rehearsal's gather is host work)
     ev_packed = torch.cuda.Event()
 
     def fb_pack(r):          # on the side stream
+        fb = cur["fb"]
         runtime.check(lib.pack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, r, world, packed.data_ptr(), side.cuda_stream), "pack")
         ev_packed.record(side)
         return packed.cpu() if c.via_host else packed
 
     def fb_unpack(src, buf):
+        fb = cur["fb"]
         if c.via_host:
             stage.copy_(buf); buf = stage
         runtime.check(lib.unpack_tiles(fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, src, world, buf.data_ptr(), side.cuda_stream), "unpack")
@@ -370,18 +394,23 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
         return b
 
     def step(i=None):
+        fb, sc = cur["fb"], cur["scene"]
         if i is not None:
             ev[i][0].record(main)
         if not c.dist_on:
-            runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, None, main.cuda_stream), "render")
+            runtime.check(lib.render_device(C.byref(cam), sc, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, None, main.cuda_stream), "render")
         else:
-            runtime.check(lib.render_device_sharded(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, rank, world, None, main.cuda_stream), "render")
+            runtime.check(lib.render_device_sharded(C.byref(cam), sc, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, TILE, rank, world, None, main.cuda_stream), "render")
         if i is not None:
             ev[i][1].record(main)
         if c.dist_on:
             side.wait_stream(main)                   # the pack reads what this render wrote
             with torch.cuda.stream(side):
-                runtime.gather_frame(fb_pack, fb_unpack, W, H, TILE, rank, world, dist, make_buffer)
+                def mark(name):
+                    if i is not None:
+                        pev[i][name].record(side); host_ph[i][name] = time.perf_counter()
+                mark("side_start")
+                runtime.gather_frame(fb_pack, fb_unpack, W, H, TILE, rank, world, dist, make_buffer, mark=mark)
             main.wait_event(ev_packed)               # the next render may overwrite the rank's own tiles once they are packed; the gather and
                                                      # rank 0's unpack (other ranks' tiles) overlap with it
 
@@ -392,6 +421,7 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
 
     if prewarm_rect:          # loads the kernel's code object with a small rectangle when a full warm-up step would take seconds
         x, y, w, h = prewarm_rect
+        fb = cur["fb"]
         runtime.check(lib.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, x, y, w, h, None, main.cuda_stream), "render")
         fence(); fb.clear()
     for _ in range(warmup):
@@ -402,31 +432,60 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     for i in range(steps):
         step(i)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
     if c.dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
     launches = max(1, st["launches"])
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+
+    # per-rank phase breakdown (N > 1): where a step's time goes on every rank, so that a scaling shortfall can be attributed
+    phases = None
+    if c.dist_on:
+        def avg(a, b, host=False):
+            if host:
+                return sum((h[b] - h[a]) * 1e3 for h in host_ph if a in h and b in h) / steps
+            return sum(p[a].elapsed_time(p[b]) for p in pev) / steps
+        mine = [own_elapsed / steps * 1e3, kernel_ms, avg("side_start", "packed"), avg("packed", "gathered"), avg("gathered", "unpacked"), avg("packed", "gathered", host=True)]
+        vec = torch.tensor(mine, dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(vec) for _ in range(world)]
+        dist.all_gather(allv, vec)
+        if rank == 0:
+            rows = [[float(x) for x in v.tolist()] for v in allv]
+            phases = {"unit": "ms per step, HIP events (render: main stream; pack / gather / unpack: second stream, overlapping the next step's render)",
+                      "per_rank": [{"rank": r, "step_wall_ms": round(v[0], 3), "render_ms": round(v[1], 3), "pack_ms": round(v[2], 3), "gather_ms": round(v[3], 3),
+                                    "unpack_ms": round(v[4], 3), "gather_host_ms": round(v[5], 3)} for r, v in enumerate(rows)],
+                      "slowest_rank": max(range(world), key=lambda r: rows[r][0]),
+                      "slowest_render_rank": max(range(world), key=lambda r: rows[r][1]),
+                      "gather_bytes_to_rank0": int(n_packed * 4 * (world - 1))}
 
     ok = None
     if check:
-        fb.clear(); fence(); step(); fence()
+        # one extra LOW-SPP step through the same shard -> pack -> gather -> unpack path into a fresh frame must equal an unsharded render bit for bit (rank 0)
+        dd = scenes.SceneDesc(**{**d.__dict__, "spp": max(split, min(d.spp, 4 * split))})
+        scene2 = scenes.build_scene(lib, dd, tree_mode=TREE_MODES[tree])
+        runtime.check(lib.set_sample_split(scene2, split), "terra_amd_set_sample_split")
+        cur["scene"], cur["fb"] = scene2, runtime.DeviceFramebuffer(W, H, device=dev)
+        fence(); step(); fence()
         if rank == 0:
             ref_fb = runtime.DeviceFramebuffer(W, H, device=dev)
-            runtime.check(lib.render_device(C.byref(cam), scene, ref_fb.pixels.data_ptr(), ref_fb.results.data_ptr(), W, H, 0, 0, W, H, None, main.cuda_stream), "render")
+            runtime.check(lib.render_device(C.byref(cam), scene2, ref_fb.pixels.data_ptr(), ref_fb.results.data_ptr(), W, H, 0, 0, W, H, None, main.cuda_stream), "render")
             torch.cuda.synchronize(dev)
+            fb = cur["fb"]
             ok = bool(torch.equal(ref_fb.pixels.view(torch.int32), fb.pixels.view(torch.int32)) and torch.equal(ref_fb.results, fb.results))
             del ref_fb
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
-    out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "check": ok,
+        fence()
+        lib.scene_destroy(scene2)
+    ti2 = runtime.TraversalInfo(); runtime.check(lib.traversal_info(scene, C.byref(ti2)))      # after the launches: what the last call actually ran
+    out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "check": ok, "phases": phases,
            "per_launch": {k: v // launches for k, v in st.items() if k != "launches"},
-           "traversal": {"fast_tree": bool(ti.fast_tree), "leaf_cull": bool(ti.leaf_cull), "note": ti.note.decode()},
+           "traversal": {"fast_tree": bool(ti.fast_tree), "leaf_cull": bool(ti.leaf_cull), "note": ti.note.decode(), "last_call": getattr(ti2, "last_call", None)},
            "lds_resident": bool(ti.lds_resident),
            "triangles": info.triangles}
     lib.scene_destroy(scene)
-    del fb
+    cur.clear()
     return out
 
 
@@ -443,6 +502,54 @@ def result_block(d, name, tree, split, steps, warmup, world, m, spp_override, in
         out["mrays_per_s"] = round(st["rays"] * world / (m["kernel_ms"] * 1e-3) / 1e6, 1)
         out["roofline"] = roofline(pmc_key(name, tree, integrator_name, split, spp_override), st, m["kernel_ms"], m["lds_resident"], world)
         out["counters_per_launch"] = st
+    return out
+
+
+def host_api(c, d, tree, split, steps):
+    """The same frame through the drop-in boundary itself: terra_render() (include/Terra.h:229) on a HOST framebuffer, so every call
+    uploads the rectangle's running sums and brings pixels + sums back (44 B/pixel over PCIe) -- SURVEY.md 8(d)'s definition of the
+    metric ("kernel + D2H of the tile included"). Two callers: one full-frame call per step, and the reference client's own pattern:
+    128-pixel tiles (satellite/include/Config.hpp:25) dealt to 8 worker threads that call terra_render() concurrently
+    (satellite/src/Renderer.cpp:70-98,316-350), with the sample split chosen per call (terra_amd_set_sample_split 0) so that a
+    tile-sized call still fills the GPU. Reported beside `value`, never as it."""
+    import threading
+    from terra_amd import api, runtime, scenes
+    lib = c.lib
+    lib.clear_error()
+    scene = scenes.build_scene(lib, d, tree_mode=TREE_MODES[tree]); cam = scenes.camera_of(d)
+    fb = api.Framebuffer(lib, d.width, d.height)              # terra_framebuffer_create: pinned host memory
+    samples = d.width * d.height * d.spp
+    out = {"pcie_bytes_per_step": d.width * d.height * 44, "steps": steps}
+
+    def timed(fn):
+        fn()                                                   # warm-up (stream + staging buffer of the calling threads)
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        return (time.perf_counter() - t) / steps
+
+    runtime.check(lib.set_sample_split(scene, split))
+    dt = timed(lambda: lib.render(C.byref(cam), scene, C.byref(fb.fb), 0, 0, d.width, d.height))
+    out["full_frame_call"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "sample_split": split}
+    tiles = [(x, y, min(128, d.width - x), min(128, d.height - y)) for y in range(0, d.height, 128) for x in range(0, d.width, 128)]
+    runtime.check(lib.set_sample_split(scene, 0))
+
+    def tile_loop():
+        def worker(k):
+            for t in tiles[k::8]:
+                lib.render(C.byref(cam), scene, C.byref(fb.fb), *t)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        [th.start() for th in ths]; [th.join() for th in ths]
+    dt = timed(tile_loop)
+    out["tile_loop_128px_8_threads"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "tiles": len(tiles), "sample_split": "automatic per call"}
+    err = runtime.last_error()
+    buf = C.create_string_buffer(256)
+    if lib.first_error(buf, 256) != 0:
+        err = err or buf.value.decode()
+    if err:
+        out["error"] = err
+    assert (fb.results["samples"] == d.spp * 2 * (steps + 1)).all(), "terra_render(): every pixel must have received every step's samples"
+    fb.destroy(); lib.scene_destroy(scene)
     return out
 
 
@@ -471,7 +578,7 @@ def main():
     if args.integrator:
         d.integrator = INTEGRATORS[args.integrator]
     integ_name = {0: "simple", 1: "direct", 2: "mis"}.get(d.integrator, str(d.integrator))
-    m = measure(c, d, args.tree, args.sample_split, args.steps, args.warmup, check=args.check)
+    m = measure(c, d, args.tree, args.sample_split, args.steps, args.warmup, check=args.check or (world > 1 and not args.no_check))
 
     if rank == 0:
         blk = result_block(d, args.workload, args.tree, args.sample_split, args.steps, args.warmup, world, m, args.spp, integ_name)
@@ -486,6 +593,10 @@ def main():
             out["sharded_equals_unsharded"] = m["check"]
         if c.dist_on:
             out["dist_backend"] = args.dist_backend
+        if m.get("phases"):
+            out["phases"] = m["phases"]
+        if world == 1 and not c.dist_on and not args.no_host_api:
+            out["host_api"] = host_api(c, d, args.tree, args.sample_split, max(1, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
         headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == 8

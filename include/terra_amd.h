@@ -66,9 +66,11 @@ uint64_t terra_amd_get_frame_seed ( HTerraScene scene );
        1e-4 box margin provably exceeds the rounding error of the slab and triangle tests; every leaf / fast-tree box contains what
        it was built around). Scenes that pass run the reference tree with the leaf-box cull (a leaf's triangle is tested only
        if the ray passes that leaf's own box) when they fit in LDS, and the fast tree otherwise. Scenes beyond that range that do not fit
-       in LDS keep the fast tree with its boxes inflated to the rounding bound, and a closest hit stands only if the reference traversal
-       would have reached it (the slab tests of its ancestors in the reference tree are replayed; DESIGN.md "Reachability mode"); the rest --
-       and calls whose camera lies outside the checked range -- run as mode 0. All produce the reference's image bit for bit; only
+       in LDS keep the fast tree (host- or device-built) with its boxes inflated to the rounding bound, and a closest hit stands only if the
+       reference traversal would have reached it (the slab tests of its ancestors in the reference tree are replayed; DESIGN.md "Reachability
+       mode"); those that do fit keep the reference tree with the leaf-box cull on leaf boxes rebuilt with that same bound. The rest
+       (non-finite or > 1e6 coordinates, trees too deep for the LDS stack) -- and calls whose camera lies outside
+       TerraAmdTraversalInfo::camera_limit -- run as mode 0. All produce the reference's image bit for bit; only
        mode 0 also reproduces its work counters. terra_amd_traversal_info() reports the decision and the reason.
    Takes effect at the next terra_scene_commit(). */
 int  terra_amd_set_tree_mode ( HTerraScene scene, int mode );
@@ -81,8 +83,19 @@ typedef struct {
     int   lds_resident;             /* 1: the whole scene (nodes, triangles, vertex properties) is staged in LDS by every block */
     float max_coordinate;           /* largest |vertex coordinate| of the committed scene */
     float max_coordinate_allowed;   /* limit of the numeric containment check */
-    char  note[192];                /* the reason, in words */
+    char  note[256];                /* the reason, in words */
+    int   last_call;                /* TerraAmdCallTraversal of the most recent render call of this scene (0: none yet). The commit-time decision above can be
+                                       overridden per call: a camera outside camera_limit sends that call down the replica traversal */
+    float camera_limit;             /* largest |camera position coordinate| for which a call keeps the commit-time decision: 13 inside the coordinate range,
+                                       8 x the scene's largest coordinate in the reachability mode */
 } TerraAmdTraversalInfo;
+typedef enum {
+    kTerraAmdCallNone = 0,
+    kTerraAmdCallReplica = 1,        /* the reference's tree, every decision of terra_bvh_traverse reproduced */
+    kTerraAmdCallLeafCull = 2,       /* ... with the leaf-box cull */
+    kTerraAmdCallFastTree = 3,
+    kTerraAmdCallFastTreeReach = 4   /* fast tree + reachability replay (scenes outside the coordinate range) */
+} TerraAmdCallTraversal;
 int  terra_amd_traversal_info ( HTerraScene scene, TerraAmdTraversalInfo* out );
 /* Who builds the fast tree at commit (replaces src/TerraBVH.c:128-244 for that tree): 0 (default) = the host, 3-axis binned SAH;
    1 = the GPU, a linear BVH (Morton sort + Karras hierarchy + bottom-up fit) built from the triangle soup already in HBM in a few
@@ -90,6 +103,11 @@ int  terra_amd_traversal_info ( HTerraScene scene, TerraAmdTraversalInfo* out );
    reference tree -- needed for the visit ranks that break depth ties, and for replica traversal -- is built on the host either way. */
 int  terra_amd_set_tree_builder ( HTerraScene scene, int builder );
 int  terra_amd_get_tree_builder ( HTerraScene scene );
+/* TEST HOOK, off by default (amount 0): at the next commit the DEVICE copy of the reference tree's boxes is shrunk by `amount` on every side, so that the
+   reference traversal -- as the device replays it -- misses triangles the watertight test would hit: the situation the reachability replay exists for and
+   that float rounding alone produces too rarely to test. While it is on, the shortcuts that rest on the commit-time containment proof (leaf-box cull, fast
+   tree inside the coordinate range) are not taken and terra_amd_traversal_info() says so. */
+int  terra_amd_debug_shrink_reference_boxes ( HTerraScene scene, float amount );
 
 /* Sample split: how many lanes share one pixel. With split = S (1, 2, 4, 8 or 16; default 1) a render call of
    spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random

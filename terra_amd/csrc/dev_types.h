@@ -78,6 +78,13 @@ struct DevMaterial {
     int32_t  any_texture;
 };
 
+struct DevReplay {                 // one level of the reachability replay (DevScene::ref_replay)
+    float    bmin[3];
+    uint32_t parent;
+    float    bmax[3];
+    uint32_t pad;
+};
+
 struct DevLight {
     uint32_t object;
     uint32_t first_tri;
@@ -104,13 +111,16 @@ struct DevScene {
     uint32_t n_fast_nodes;
     int32_t  fast_max_stack;
     // scenes outside the coordinate range of the containment proof (DESIGN.md "Reachability"): the fast tree (boxes inflated to the rounding bound) finds the
-    // candidates, and one is accepted only if the REFERENCE traversal would have reached it: ref_parent[node] = parent << 1 | child slot (node 0 = root),
-    // fast_leaf_parent[i] = the reference node whose leaf child fast triangle i is
-    const uint32_t*    ref_parent;
+    // candidates, and one is accepted only if the REFERENCE traversal would have reached it, i.e. if the slab tests of its ancestors in the reference tree pass.
+    // ref_replay[q] (DevReplay, 32 B) = the box the reference tests before it visits inner node q -- stored in q's parent -- and that parent's index, so that one
+    // 32-byte fetch gives a level's test AND the way up (node 0 = the root: never tested); fast_leaf_parent[i] = the reference node whose leaf child fast triangle i is
+    const struct DevReplay* ref_replay;
     const uint32_t*    fast_leaf_parent;
-    // fast_leaf_mask[i]: bit L set = the box of the L-th node on the way up from fast triangle i's leaf (L = 0: the leaf's node, as its parent stores it) does NOT contain
-    // the triangle's extent with a clearance above the rounding bound, so its slab test has to be replayed; a clear bit = that test cannot fail for a ray that hits the
-    // triangle (the containment argument, at the scene's scale). Bit 31 stands for every level from 31 up.
+    // fast_leaf_mask[i]: bit L set = the slab test of the L-th node on the way up from fast triangle i's leaf (L = 0: the leaf's node) has to be replayed for a ray that
+    // hits the triangle. A clear bit = it cannot fail: either the box contains the triangle's extent with a clearance above the rounding bound (the containment
+    // argument, at the scene's scale), or it contains the box of level L - 1 component by component -- then, for a ray whose inverse direction is finite and non-zero,
+    // (b - o) * inv being monotone in b makes "level L - 1 passes" imply "level L passes" in the very same float arithmetic. Rays that are not regular replay every
+    // level. Bit 31 stands for every level from 31 up.
     const uint32_t*    fast_leaf_mask;
     uint32_t           reach;
     // environment lighting (terra_amd_set_environment_lighting; off = the reference's behaviour):
@@ -149,9 +159,16 @@ struct DevRenderParams {
     // of chunk_spp, one lane per (pixel, chunk); chunk j draws from the streams keyed (pixel, samples_so_far + j*chunk_spp)
     // and its radiance sum goes to partials[(j * blocks + block) * 256 + thread] = {sum.xyz, rand calls};
     // terra_resolve_kernel then adds the chunk sums to the pixel IN CHUNK ORDER -- exactly what `split`
-    // successive calls of chunk_spp samples produce. split == 1: one kernel, no partials.
+    // successive calls of chunk_spp samples produce. split == 1: one chunk, the call's own sum (src/Terra.c:551-572).
     uint32_t split, split_log2, chunk_spp;
     float4*  partials;
+    // job space of the persistent render grid (render_kernels.hip "jobs"): job_blocks virtual 256-thread blocks = (16x16 pixel blocks of the
+    // shard) * split; *job_queue (zeroed before the launch) hands out the jobs beyond the ones the launched lanes start with
+    uint32_t job_blocks;
+    uint32_t* job_queue;
+    // the job decode's divisions by launch constants as multiplications: ceil(2^32 / d) (0 for d == 1) for d = (blocks per tile)^2, tiles per row of the
+    // rectangle, blocks per tile row (the host refuses a launch in which some product n * d could reach 2^32)
+    uint32_t job_div_bpt2, job_div_tiles_x, job_div_bpt, job_tiles_x;
     uint32_t bounces;
     int32_t  integrator;
     int32_t  tonemap;

@@ -33,6 +33,7 @@ hipError_t terra_unit_halton ( int first, int n, float* out2 );
 hipError_t terra_unit_distribution_1d ( const float* f, uint32_t n, float* cdf, float* integral, uint32_t* monotone, const float* e, int m, float* x, float* pdf, uint32_t* idx );
 hipError_t terra_unit_distribution_2d ( const float* f, uint32_t nx, uint32_t ny, float* cdf, float* integrals, float* mcdf, uint32_t* monotone, const float* e12, int m, float* xy2, float* pdf );
 // the fast tree built on the GPU (tree_build_device.hip): device pointers; out_nodes holds up to n - 1 nodes, out_tris n triangles
-hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream );
+// extra_margin: added to the +-1e-4 triangle boxes on every side (0 inside the coordinate range; the rounding bound of the reachability mode outside it)
+hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, float extra_margin, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream );
 // (min, max) -> (centre, half extent) child boxes, in place: the form the MODE-2 kernels traverse (tree_build_device.hip)
 hipError_t terra_fast_nodes_center_extent ( DevNode* nodes, uint32_t n, hipStream_t stream );

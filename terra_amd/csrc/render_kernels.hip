@@ -47,9 +47,10 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t
 // Builds the block's Tracer: carves the dynamic LDS, stages the scene prefix the host
 // planned (DevRenderParams.lds_*), and leaves every thread with its own stack / leaf
 // list column. Called by all 256 threads (it contains the block barrier).
-// per-thread words parked in LDS between uses (indexed [word][thread] like the stack): the pixel's
-// radiance sum of this call, touched once per path
-#define TERRA_AUX_WORDS 3
+// per-thread words parked in LDS between uses (indexed [word][thread] like the stack): the radiance sum of the lane's
+// current job (touched once per path), the job's number and the lane's draw count when the job started (read at its end), and a row
+// that holds each wave's pool of claimed jobs (render_kernels.hip "jobs")
+#define TERRA_AUX_WORDS 6
 #ifndef TERRA_CHECK_SHRINK
 #define TERRA_CHECK_SHRINK 0
 #endif
@@ -110,8 +111,9 @@ TD bool block_pixel ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint
     return lx < p.w && ly < p.h;
 }
 
-// Second kernel of a split render: pixel += chunk sums, in chunk order (float adds in the order `split`
-// successive calls would make them), then the same exposure / tonemap / store as the single-kernel path.
+// Second kernel of every render: pixel += chunk sums, in chunk order (float adds in the order `split` successive calls
+// would make them; split == 1: the one sum of the call, reference src/Terra.c:570-572), then exposure / tonemap / store
+// (src/Terra.c:574-630). gridDim.x = the job space's 16x16 pixel blocks.
 __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams p ) {
     uint32_t px, py;
     if ( !block_pixel ( p, blockIdx.x, threadIdx.x, px, py ) ) return;
@@ -281,6 +283,99 @@ TD V3 shade_surface ( const Tracer& T, const Ray& ray, const Closest& best, Surf
 // a path ended: its radiance joins the pixel's sum of this call (parked in LDS, see TERRA_AUX_WORDS)
 TD void deposit ( float* acc_lds, V3 Lo ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_lds[256] = acc_lds[256] + Lo.y; acc_lds[512] = acc_lds[512] + Lo.z; }
 
+// ---- jobs ------------------------------------------------------------------------------------------------------------
+// A JOB is one (pixel, chunk) pair: chunk_spp camera samples of one pixel, traced in order with the streams keyed (pixel,
+// samples already in the pixel + chunk * chunk_spp) and summed from zero into partials[] (DevRenderParams::split; split == 1: the
+// call's one sum per pixel). Jobs are numbered like the threads of a plain launch would be -- job = virtual block * 256 + virtual
+// thread, virtual block = (16x16 pixel block of the shard) * split + chunk -- and the grid is PERSISTENT: at most as many blocks
+// as the GPU holds at once (terra_launch_render). A wave starts with the 64 jobs of its own index and, when those are handed out,
+// claims the next unclaimed batch of 64 from a queue word in HBM (one atomic per 64 jobs); its lanes take jobs from the wave's
+// pool (two words of LDS) whenever their own is finished. What a job computes does not depend on which lane runs it, so the frame
+// is the plain launch's bit for bit; what changes is that a wave's 64 lanes no longer wait for the slowest of 64 fixed pixels
+// (paths have random lengths: with 64-sample chunks 13 % of the lane time of the Cornell frame was spent in that ramp-down,
+// profiles/r02_measurements/phase_cornell.log) and that the launch has no tail of half-empty rounds.
+// Exit: the queue only grows; a lane that finds the pool empty and the queue beyond the job space leaves the loop for good.
+struct Jobs { uint32_t px, py, s; bool exhausted; };
+
+#ifndef TERRA_JOB_FETCH_MIN      // (coupled loop) lanes at a job boundary switch jobs together once this many wait there -- or no lane of the wave is tracing:
+#define TERRA_JOB_FETCH_MIN 4    // the switch (pixel decode, stream keys: ~250 instructions) then runs for several lanes at once
+#endif
+#define TERRA_JOB_BATCH 64u
+#define TERRA_JOB_NONE 0xffffffffu
+
+// n / d for the launch-constant divisors of the job decode: q = (n * magic) >> 32 with magic = ceil(2^32 / d), exact while n * d < 2^32 (the host checks);
+// magic == 0 stands for d == 1
+TD uint32_t magic_div ( uint32_t n, uint32_t magic ) { return magic ? __umulhi ( n, magic ) : n; }
+// block_pixel() for a job, with the divisions by launch constants done by multiplication (p.job_div_*; the host refuses launches whose dividends are too large
+// for that -- no plain-division fallback here: its hoisted reciprocals would sit in registers through the whole render loop)
+TD bool job_pixel ( const DevRenderParams& p, uint32_t job, uint32_t& px, uint32_t& py, uint32_t& chunk ) {
+    const uint32_t vblock = job >> 8, tid = job & 255u;
+    chunk = vblock & ( p.split - 1 );
+    const uint32_t blk = vblock >> p.split_log2;
+    const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
+    const uint32_t k = magic_div ( blk, p.job_div_bpt2 ), b = blk - k * bpt2;
+    const uint32_t t = p.rank + k * p.world;
+    const uint32_t ty = magic_div ( t, p.job_div_tiles_x ), tx = t - ty * p.job_tiles_x;
+    const uint32_t by = magic_div ( b, p.job_div_bpt ), bx = b - by * bpt;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t lx = tx * p.tile_size + bx * 16 + ( wave & 1 ) * 8 + ( lane & 7 );
+    const uint32_t ly = ty * p.tile_size + by * 16 + ( wave >> 1 ) * 8 + ( lane >> 3 );
+    px = p.x + lx; py = p.y + ly;
+    return lx < p.w && ly < p.h;
+}
+// aux: the lane's parked words (TERRA_AUX_WORDS rows of 256): [0], [256], [512] the job's radiance sum; [768] the job; [1024] the lane's draw count at the job's
+// start; row 5 holds, per wave, the pool {next job, end} at [1280 + 64 * wave + 0 / 1] relative to thread 0's column
+TD uint32_t* job_pool_of_wave ( float* aux_of_thread ) { return reinterpret_cast<uint32_t*> ( aux_of_thread - threadIdx.x ) + 1280 + ( threadIdx.x & ~63u ); }
+TD void job_init_lane ( const DevRenderParams& p, float* aux ) {
+    reinterpret_cast<uint32_t*> ( aux ) [768] = TERRA_JOB_NONE;
+    if ( ( threadIdx.x & 63u ) == 0 ) {       // the wave's first pool: the jobs of its own index
+        uint32_t* pool = job_pool_of_wave ( aux );
+        const uint32_t total = p.job_blocks * 256u, first = blockIdx.x * 256u + threadIdx.x;
+        pool[0] = first < total ? first : total; pool[1] = first + TERRA_JOB_BATCH < total ? first + TERRA_JOB_BATCH : total;
+    }
+}
+// Job boundary, for whichever lanes of the wave call it together: store the finished job's sum, take the next job from the wave's pool (claiming a new batch from
+// the queue when it runs dry), set up its pixel and streams. Leaves j.s == chunk_spp when the job is a pixel outside the rectangle (the job space is made of whole
+// 16x16 blocks): the lane simply asks again. Only the calling lanes' registers change; the pool lives in LDS because the lanes that are not here must see it move too.
+template <int COUNT>
+TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& rs, const Counters& c ) {
+    uint32_t* auxu = reinterpret_cast<uint32_t*> ( aux );
+    const uint32_t fin = auxu[768];
+    if ( fin != TERRA_JOB_NONE ) {
+        const uint32_t vblock = fin >> 8, chunk = vblock & ( p.split - 1 ), blk = vblock >> p.split_log2;
+        p.partials[ ( ( size_t ) chunk * ( p.job_blocks >> p.split_log2 ) + blk ) * 256 + ( fin & 255u )] = make_float4 ( aux[0], aux[256], aux[512], __uint_as_float ( COUNT == 2 ? c.rand_calls - auxu[1024] : 0u ) );
+        auxu[768] = TERRA_JOB_NONE;
+    }
+    uint32_t* pool = job_pool_of_wave ( aux );
+    const unsigned long long m = __ballot ( 1 );                 // the lanes here
+    const uint32_t lane = threadIdx.x & 63u, n = ( uint32_t ) __popcll ( m ), ahead = ( uint32_t ) __popcll ( m & ( ( 1ull << lane ) - 1ull ) );
+    const uint32_t total = p.job_blocks * 256u;
+    uint32_t next = pool[0], end = pool[1];
+    const uint32_t take = n < end - next ? n : end - next;
+    uint32_t job = next + ahead;
+    bool got = ahead < take;
+    next += take;
+    if ( take < n && next < total ) {                            // the pool ran dry: the next batch of the queue (one atomic by the first lane here), for the lanes still without a job
+                                                                 // (next == total: an earlier batch already came back beyond the job space -- nothing is left, no need to ask again)
+        uint32_t base = 0;
+        if ( ahead == 0 ) base = atomicAdd ( p.job_queue, TERRA_JOB_BATCH );
+        base = gridDim.x * 256u + ( uint32_t ) __builtin_amdgcn_readfirstlane ( ( int ) base );
+        next = base < total ? base : total; end = base + TERRA_JOB_BATCH < total ? base + TERRA_JOB_BATCH : total;
+        const uint32_t take2 = n - take < end - next ? n - take : end - next;
+        if ( !got ) { job = next + ( ahead - take ); got = ahead - take < take2; }
+        next += take2;
+    }
+    if ( ahead == 0 ) { pool[0] = next; pool[1] = end; }
+    if ( !got ) { j.exhausted = true; return; }                  // the queue is monotone: a batch that does not cover the askers means nothing is left, ever
+    uint32_t chunk;
+    if ( !job_pixel ( p, job, j.px, j.py, chunk ) ) return;
+    const int prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( j.py - p.st_y ) * p.st_pitch + ( j.px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
+    rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) j.py * p.fb_w + j.px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
+    aux[0] = 0.f; aux[256] = 0.f; aux[512] = 0.f; auxu[768] = job;
+    if ( COUNT == 2 ) auxu[1024] = c.rand_calls;
+    j.s = 0;
+}
+
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
@@ -289,23 +384,14 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     T0.faults = p.counters + kCtrFaults;
     const Tracer T = T0;
 
-    // block -> (own tile, 16x16 block in tile) -> pixel
-    // (with a sample split the consecutive blocks chunk 0..split-1 of one 16x16 pixel block)
-    const uint32_t chunk = blockIdx.x & ( p.split - 1 ), blk = blockIdx.x >> p.split_log2;
-    uint32_t px, py;
-    const bool valid = block_pixel ( p, blk, tid, px, py );
-
-    DevResult* results = reinterpret_cast<DevResult*> ( p.results );
-    // only the sample count is needed up front (it keys the streams); the running sum is re-read at the end
-    const int prior_samples = valid ? results[ ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x )].samples : 0;
-    PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
+    PixelStreams rs = trng_pixel_streams ( 0, 0, 0 );
     Counters c = counters_zero();
-
-    float* acc_lds = reinterpret_cast<float*> ( T.stack - tid ) + ( p.stack_depth + p.leaf_cap ) * TERRA_COL + tid;     // the parked words follow the leaf list: acc.x/y/z at [0], [256], [512]
-    acc_lds[0] = 0.f; acc_lds[256] = 0.f; acc_lds[512] = 0.f;
+    float* acc_lds = reinterpret_cast<float*> ( T.stack - tid ) + ( p.stack_depth + p.leaf_cap ) * TERRA_COL + tid;     // the parked words follow the leaf list
+    job_init_lane ( p, acc_lds );       // (make_tracer's barrier came before; a wave only ever touches its own pool words)
+    Jobs jb; jb.px = jb.py = 0; jb.s = p.chunk_spp; jb.exhausted = false;
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     Ray ray = make_ray ( v3 ( 0, 0, 0 ), v3 ( 0, 0, 1 ) );
-    uint32_t s = 0, bounce = 0;
+    uint32_t bounce = 0;
     const V3 cam_pos = v3p ( p.cam_pos );
 
     if constexpr ( TERRA_DECOUPLED_MIS ( INTEGRATOR, MODE, KINDS ) ) {
@@ -313,12 +399,13 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // order -- A: the ray to the light sample, B: the BSDF-sampled ray (mis_prepare / mis_finish_b).
         LaneTraversal lt = lane_traversal_idle ( T, ray );
         int job = 0;                                             // 0 path segment, 1 shadow ray A, 2 shadow ray B
-        bool done = !valid, have_ray = false, cont = false;
+        bool done = false, have_ray = false, cont = false;
         MisPending pend; pend.a_vis = pend.a_hid = pend.f2 = pend.p = pend.t_before = v3 ( 0, 0, 0 ); pend.expected = 0; pend.bpdf2 = pend.cos2 = 0.f; pend.light_object = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 ), b_o = v3 ( 0, 0, 0 ), b_d = v3 ( 0, 0, 1 ), lo_i = v3 ( 0, 0, 0 );
         for ( ;; ) {
             if ( !lt.traversing && !done && ! ( have_ray && lane_traversal_recheck<MODE> ( T, ray, lt ) ) ) {
                 bool start = false;
+                V3 ro = v3 ( 0, 0, 0 ), rd = v3 ( 0, 0, 1 );              // the ray that starts (its reciprocals are taken once, below)
                 if ( have_ray && job != 0 ) {
                     Ray r = ray; r.o = r.o + r.d * 0.001f;
                     const bool hit = lt.best.tri != 0xffffffffu;
@@ -332,11 +419,11 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     }
                     if ( job == 1 ) {                            // A came back: pick its outcome, send B
                         lo_i = tri_s == pend.expected ? pend.a_vis : pend.a_hid;
-                        ray = make_ray ( b_o, b_d ); job = 2; start = true;
+                        ro = b_o; rd = b_d; job = 2; start = true;
                     } else {                                     // B came back: the integrator's value is complete
                         Lo = Lo + mis_finish_b<MODE> ( T, pend, lo_i, hit, object, tri_s, point, lsf, ray.d );
                         job = 0;
-                        if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
+                        if ( cont ) { ro = cont_o; rd = cont_d; start = true; }
                         else { deposit ( acc_lds, Lo ); have_ray = false; }
                     }
                 } else if ( have_ray ) {                         // a path segment came back
@@ -349,23 +436,23 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         b_o = point + sf.normal * 0.0001f;        // surface_ray ( sf, point, bsdf_dir, 1.f ) without the divisions
                         cont = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
                         cont_o = point + sf.normal * 0.0001f;     // (the divisions of surface_ray are redone when the ray starts)
-                        ray = ray_a; job = 1; start = true;
+                        ro = ray_a.o; rd = ray_a.d; job = 1; start = true;
                     } else {
                         if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
                         deposit ( acc_lds, Lo ); have_ray = false;
                     }
                 }
                 if ( !start ) {
-                    if ( s == p.chunk_spp ) done = true;
-                    else {
+                    if ( jb.s == p.chunk_spp ) { job_next<COUNT> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
+                    if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
-                        ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
-                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; job = 0; start = true;
+                        ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; job = 0; start = true;
                     }
                 }
-                if ( start ) { lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
+                if ( start ) { ray = make_ray ( ro, rd ); lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
             }
-            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) ) break;      // nobody traversing => everybody is done
+            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) && __all ( done ) ) break;      // nobody traversing and no job left
         }
     } else if constexpr ( TERRA_DECOUPLED_DIRECT ( INTEGRATOR, MODE, KINDS ) ) {
         // Decoupled loop for the Direct integrator. A lane's ray in flight is either a path segment (MAIN) or the shadow
@@ -374,12 +461,13 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // order -- parks the continuation ray and sends the shadow ray; when that returns, the matching outcome is added
         // and the continuation (or the pixel's next sample) starts. Same rays, same draws, same sums as integrate_direct.
         LaneTraversal lt = lane_traversal_idle ( T, ray );
-        bool done = !valid, have_ray = false, shadow = false, cont = false;
+        bool done = false, have_ray = false, shadow = false, cont = false;
         DirectPending pend; pend.vis = pend.hid = v3 ( 0, 0, 0 ); pend.expected = 0;
         V3 cont_o = v3 ( 0, 0, 0 ), cont_d = v3 ( 0, 0, 1 );
         for ( ;; ) {
             if ( !lt.traversing && !done && ! ( have_ray && lane_traversal_recheck<MODE> ( T, ray, lt ) ) ) {
                 bool start = false;
+                V3 ro = v3 ( 0, 0, 0 ), rd = v3 ( 0, 0, 1 );
                 if ( have_ray && shadow ) {                      // the shadow ray came back
                     const uint32_t tri_s = hit_soup_index<MODE> ( T, lt.best.tri );
                     if ( tri_s != 0xffffffffu ) {                   // (its hit counts as a surface init, as in the coupled form)
@@ -388,7 +476,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     }
                     Lo = Lo + ( tri_s == pend.expected ? pend.vis : pend.hid );
                     shadow = false;
-                    if ( cont ) { ray = make_ray ( cont_o, cont_d ); start = true; }
+                    if ( cont ) { ro = cont_o; rd = cont_d; start = true; }
                     else { deposit ( acc_lds, Lo ); have_ray = false; }
                 } else if ( have_ray ) {                         // a path segment came back
                     if ( lt.best.tri != 0xffffffffu ) {
@@ -398,24 +486,24 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Ray shadow_ray;
                         pend = direct_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
                         cont = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
-                        cont_o = point + sf.normal * 0.0001f;     // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are redone when the ray starts
-                        ray = shadow_ray; shadow = true; start = true;
+                        cont_o = point + sf.normal * 0.0001f;     // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are taken when the ray starts
+                        ro = shadow_ray.o; rd = shadow_ray.d; shadow = true; start = true;
                     } else {
                         if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
                         deposit ( acc_lds, Lo ); have_ray = false;
                     }
                 }
-                if ( !start ) {                                  // the path ended (or none was started yet): the pixel's next sample
-                    if ( s == p.chunk_spp ) done = true;
-                    else {
+                if ( !start ) {                                  // the path ended (or none was started yet): the pixel's next sample, or the lane's next job
+                    if ( jb.s == p.chunk_spp ) { job_next<COUNT> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
+                    if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
-                        ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
-                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; start = true;
+                        ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; start = true;
                     }
                 }
-                if ( start ) { lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
+                if ( start ) { ray = make_ray ( ro, rd ); lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
             }
-            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) ) break;      // nobody traversing => everybody is done
+            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) && __all ( done ) ) break;      // nobody traversing and no job left
         }
     } else if constexpr ( TERRA_DECOUPLED ( INTEGRATOR, MODE ) ) {
         // Decoupled loop (scenes read from global memory, integrators without nested raycasts): a lane is either
@@ -424,10 +512,11 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         // pixel's next camera sample) while the others keep their traversal state. Per pixel nothing changes: same
         // rays, same stream draws, same accumulation order.
         LaneTraversal lt = lane_traversal_idle ( T, ray );
-        bool done = !valid, have_ray = false;
+        bool done = false, have_ray = false;
         for ( ;; ) {
             if ( !lt.traversing && !done && ! ( have_ray && lane_traversal_recheck<MODE> ( T, ray, lt ) ) ) {
                 bool next = false;
+                V3 ro = v3 ( 0, 0, 0 ), rd = v3 ( 0, 0, 1 );
                 if ( have_ray ) {
                     if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
@@ -435,68 +524,64 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         V3 wo = neg ( ray.d ), wi;
                         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, point, wo, throughput, bounce, rs.b, c );
                         next = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
-                        if ( next ) ray = surface_ray ( sf, point, wi, 1.f );
+                        if ( next ) { ro = point + sf.normal * 0.0001f; rd = wi; }       // surface_ray ( sf, point, wi, 1.f ); its reciprocals are taken below
                     } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {
                         throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
                         Lo = Lo + throughput;
                     }
-                    if ( !next ) deposit ( acc_lds, Lo );
+                    if ( !next ) { deposit ( acc_lds, Lo ); have_ray = false; }
                 }
                 if ( !next ) {
-                    if ( s == p.chunk_spp ) { done = true; have_ray = false; }
-                    else {
+                    if ( jb.s == p.chunk_spp ) { job_next<COUNT> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
+                    if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
-                        ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
-                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++s; next = true;
+                        ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                        Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; next = true;
                     }
                 }
-                if ( next ) { lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
+                if ( next ) { ray = make_ray ( ro, rd ); lane_traversal_start<COUNT> ( T, ray, lt, c ); have_ray = true; }
             }
-            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) ) break;      // nobody traversing => everybody is done
+            if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) && __all ( done ) ) break;      // nobody traversing and no job left
         }
     } else {
+    // Coupled loop (LDS-resident scenes; Direct / MIS everywhere their decoupled forms are off): every lane that holds a live path traces one
+    // ray per iteration; a lane whose path ended starts its pixel's next sample in the same iteration, or its next job.
     bool alive = false;
+    V3 ro = v3 ( 0, 0, 0 ), rd = v3 ( 0, 0, 1 );                     // origin / direction of the lane's next ray; the reciprocals are taken in ONE place for camera and continuation rays
     while ( true ) {
+        const bool any_alive = __any ( alive );
         if ( !alive ) {
-            if ( !valid || s == p.chunk_spp ) break;
-            PS_WAVE ( c, kPsCamIter ); PS_LANE ( c, kPsCamLanes );
-            float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
-            ray = make_ray ( cam_pos, camera_sample ( p, px, py, r1, r2 ) );
-            Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++s;
+            // (a lane waits at the boundary until TERRA_JOB_FETCH_MIN lanes do, or nobody is tracing: the switch then serves several lanes per execution)
+            if ( jb.s == p.chunk_spp && ( TERRA_JOB_FETCH_MIN <= 1 || !any_alive || __popcll ( __ballot ( jb.s == p.chunk_spp ) ) >= TERRA_JOB_FETCH_MIN ) ) job_next<COUNT> ( p, acc_lds, jb, rs, c );
+            if ( jb.exhausted ) break;
+            if ( jb.s != p.chunk_spp ) {
+                PS_WAVE ( c, kPsCamIter ); PS_LANE ( c, kPsCamLanes );
+                float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
+                ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++jb.s;
+            }
         }
-        Surface sf;
-        PS_WAVE ( c, kPsRayIter ); PS_LANE ( c, kPsRayLanes );
-        RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
-        bool end = !h.hit;
-        if ( h.hit ) {
-            PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
-            V3 wo = neg ( ray.d ), wi;
-            Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
-            end = !path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
-            if ( !end ) ray = surface_ray ( sf, h.point, wi, 1.f );
-        } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
-            throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
-            Lo = Lo + throughput;
+        if ( alive ) {
+            ray = make_ray ( ro, rd );
+            Surface sf;
+            PS_WAVE ( c, kPsRayIter ); PS_LANE ( c, kPsRayLanes );
+            RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
+            bool end = !h.hit;
+            if ( h.hit ) {
+                PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
+                V3 wo = neg ( ray.d ), wi;
+                Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
+                end = !path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
+                if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }      // surface_ray ( sf, h.point, wi, 1.f ): its make_ray is the one at the top of this block
+            } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
+                throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
+                Lo = Lo + throughput;
+            }
+            if ( end ) { deposit ( acc_lds, Lo ); alive = false; }
         }
-        if ( end ) { deposit ( acc_lds, Lo ); alive = false; }
     }
     }
 
-    if ( p.split > 1 ) {      // this chunk's sum; terra_resolve_kernel folds the chunks into the pixel in order
-        p.partials[ ( ( size_t ) chunk * ( gridDim.x >> p.split_log2 ) + blk ) * 256 + tid] = make_float4 ( acc_lds[0], acc_lds[256], acc_lds[512], __uint_as_float ( COUNT == 2 ? c.rand_calls : 0u ) );
-    } else if ( valid ) {
-        const size_t pix = ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x );
-        const DevResult prior = results[pix];
-        DevResult out;
-        out.acc[0] = acc_lds[0] + prior.acc[0]; out.acc[1] = acc_lds[256] + prior.acc[1]; out.acc[2] = acc_lds[512] + prior.acc[2];
-        out.samples = prior.samples + ( int ) p.spp;
-        results[pix] = out;
-        float n = ( float ) out.samples;
-        V3 color = v3 ( out.acc[0] / n, out.acc[1] / n, out.acc[2] / n ) * p.exposure;
-        color = tonemap ( color, p.tonemap, p.gamma );
-        p.pixels[3 * pix + 0] = color.x; p.pixels[3 * pix + 1] = color.y; p.pixels[3 * pix + 2] = color.z;
-        if ( COUNT == 2 && p.rand_calls ) p.rand_calls[pix] = c.rand_calls;
-    }
     if ( COUNT ) wave_flush_counters<COUNT> ( c, p.counters, p.lean_attr_per_hit );
     if ( COUNT == 2 && p.leaf_cull ) {
         unsigned long long x = c.tri_culled;
@@ -579,42 +664,65 @@ void terra_plan_lds ( DevRenderParams& p ) {
     }
 }
 
+// blocks of one kernel instance the GPU holds at once (occupancy x CUs), cached per (kernel, LDS size): the persistent grid
+static uint32_t resident_blocks ( const void* fn, size_t lds ) {
+    struct Key { const void* fn; size_t lds; int dev; uint32_t blocks; };
+    static thread_local Key cache[8]; static thread_local int used = 0;
+    int dev = 0; ( void ) hipGetDevice ( &dev );
+    for ( int i = 0; i < used; ++i ) if ( cache[i].fn == fn && cache[i].lds == lds && cache[i].dev == dev ) return cache[i].blocks;
+    int per_cu = 0, cus = 0;
+    if ( hipOccupancyMaxActiveBlocksPerMultiprocessor ( &per_cu, fn, 256, lds ) != hipSuccess || per_cu < 1 ) { ( void ) hipGetLastError(); per_cu = 1; }
+    if ( hipDeviceGetAttribute ( &cus, hipDeviceAttributeMultiprocessorCount, dev ) != hipSuccess || cus < 1 ) { ( void ) hipGetLastError(); cus = 256; }
+    const uint32_t blocks = ( uint32_t ) per_cu * ( uint32_t ) cus;
+    Key& k = cache[used < 8 ? used++ : 7]; k.fn = fn; k.lds = lds; k.dev = dev; k.blocks = blocks;
+    return blocks;
+}
+#ifndef TERRA_PERSISTENT      // 0: one block per virtual block, as a plain launch (A/B of the job queue)
+#define TERRA_PERSISTENT 1
+#endif
+template <int I, int COUNT, int MODE, int KINDS>
+static hipError_t launch_instance ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
+    auto fn = terra_render_kernel<I, COUNT, MODE, KINDS>;
+    uint32_t grid = p.job_blocks;
+    if ( TERRA_PERSISTENT ) { const uint32_t cap = resident_blocks ( reinterpret_cast<const void*> ( fn ), lds ); if ( grid > cap ) grid = cap; }
+    hipLaunchKernelGGL ( fn, dim3 ( grid ), dim3 ( 256 ), lds, stream, p );
+    return hipGetLastError();
+}
 template <int I, int MODE, int KINDS>
-static hipError_t launch_kinds ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
+static hipError_t launch_kinds ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
     // lean counting is only valid for integrators without light sampling (every hit = 4 draws)
     constexpr bool lean_ok = I == 0 || I == 3 || I == 4 || I == 5;
-    if ( lean_ok && p.count_level == 1 ) hipLaunchKernelGGL ( ( terra_render_kernel<I, lean_ok ? 1 : 2, MODE, KINDS> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
-    else hipLaunchKernelGGL ( ( terra_render_kernel<I, 2, MODE, KINDS> ), dim3 ( blocks ), dim3 ( 256 ), lds, stream, p );
-    return hipGetLastError();
+    if ( lean_ok && p.count_level == 1 ) return launch_instance<I, lean_ok ? 1 : 2, MODE, KINDS> ( p, lds, stream );
+    return launch_instance<I, 2, MODE, KINDS> ( p, lds, stream );
 }
 // kinds present in the scene -> the leanest compiled variant that covers them: diffuse only (1), diffuse + Phong (3: what
 // OBJ/MTL scenes map to, satellite/src/Scene.cpp:193-230), or everything (GGX, glass, textures, environment term)
 template <int I, int MODE>
-static hipError_t launch_mode ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
-    if ( p.bsdf_kinds == 1 ) return launch_kinds<I, MODE, 1> ( p, blocks, lds, stream );
-    if ( ( p.bsdf_kinds & ~3u ) == 0 ) return launch_kinds<I, MODE, 3> ( p, blocks, lds, stream );
-    return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, blocks, lds, stream );
+static hipError_t launch_mode ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
+    if ( p.bsdf_kinds == 1 ) return launch_kinds<I, MODE, 1> ( p, lds, stream );
+    if ( ( p.bsdf_kinds & ~3u ) == 0 ) return launch_kinds<I, MODE, 3> ( p, lds, stream );
+    return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, lds, stream );
 }
 template <int I>
-static hipError_t launch_one ( const DevRenderParams& p, uint32_t blocks, size_t lds, hipStream_t stream ) {
-    if ( p.lds_mode == 1 ) return launch_mode<I, 1> ( p, blocks, lds, stream );
-    if ( p.lds_mode == 2 ) return launch_mode<I, 2> ( p, blocks, lds, stream );
-    return launch_mode<I, 0> ( p, blocks, lds, stream );
+static hipError_t launch_one ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
+    if ( p.lds_mode == 1 ) return launch_mode<I, 1> ( p, lds, stream );
+    if ( p.lds_mode == 2 ) return launch_mode<I, 2> ( p, lds, stream );
+    return launch_mode<I, 0> ( p, lds, stream );
 }
 
+// p.job_blocks, p.job_queue (zeroed on `stream` by the caller), p.partials must be set (scene_host.cpp launch_render)
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {
-    uint32_t bpt = p.tile_size / 16;
-    uint32_t blocks = own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt * p.split;
-    if ( blocks == 0 ) return hipSuccess;
+    if ( p.job_blocks == 0 ) return hipSuccess;
+    if ( !p.job_queue || !p.partials ) return hipErrorInvalidValue;
     size_t lds = terra_lds_bytes ( p );
     switch ( p.integrator ) {
-        case 0: return launch_one<0> ( p, blocks, lds, stream );
-        case 1: return launch_one<1> ( p, blocks, lds, stream );
-        case 2: return launch_one<2> ( p, blocks, lds, stream );
-        case 3: return launch_one<3> ( p, blocks, lds, stream );
-        case 4: return launch_one<4> ( p, blocks, lds, stream );
-        case 5: return launch_one<5> ( p, blocks, lds, stream );
-        case 6: return launch_one<6> ( p, blocks, lds, stream );
+        case 0: return launch_one<0> ( p, lds, stream );
+        case 1: return launch_one<1> ( p, lds, stream );
+        case 2: return launch_one<2> ( p, lds, stream );
+        case 3: return launch_one<3> ( p, lds, stream );
+        case 4: return launch_one<4> ( p, lds, stream );
+        case 5: return launch_one<5> ( p, lds, stream );
+        case 6: return launch_one<6> ( p, lds, stream );
         default: return hipErrorInvalidValue;
     }
 }

@@ -245,6 +245,8 @@ struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 #endif
 #define TERRA_REACH_MAX_COORD 1e6f       // beyond it (c - o) x 2^100 (the fast tree's clamped slab test) approaches the binary32 range: replica
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
+#define TERRA_FAST_STACK_LDS_LIMIT ( 64 * 1024 )   // dynamic LDS a block may ask for without an opt-in; a fast-tree launch needs (depth + aux words) KB + its staged node prefix
+#define TERRA_FAST_STACK_AUX_KB 5                   // render_kernels.hip TERRA_AUX_WORDS
 struct Scene {
     TerraSceneOptions opts, new_opts;
     TerraObject* objects = nullptr; size_t objects_pop = 0, objects_cap = 0;
@@ -270,13 +272,16 @@ struct Scene {
     bool fast_on_device = false;        // the fast tree of the last upload was built on the device
     bool cull_ok = false;               // leaf-box cull allowed for this scene (subject to the per-call camera check)
     bool reach = false;                 // outside the coordinate range: fast tree + reference reachability check (camera within reach_limit, checked per call)
+    bool reach_cull = false;            // outside the coordinate range, LDS-resident: reference tree, leaf-box cull on leaf boxes inflated to the rounding bound (same camera limit)
     float reach_limit = 0.f;
+    std::atomic<int> last_call { 0 };   // TerraAmdTraversalInfo::last_call: the traversal the most recent render call actually ran
     float coord_max = 0.f;              // largest |coordinate| of any vertex
     std::string tree_note;              // why the automatic mode chose what it chose
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
+    float test_shrink_reference_boxes = 0.f;       // terra_amd_debug_shrink_reference_boxes (tests only): the device copy of the reference tree's boxes is shrunk by this much
 };
 
 static Scene* S ( HTerraScene h ) { return ( Scene* ) h; }
@@ -324,6 +329,12 @@ extern "C" int terra_amd_set_tree_builder ( HTerraScene h, int builder ) {
     return 0;
 }
 extern "C" int terra_amd_get_tree_builder ( HTerraScene h ) { return S ( h )->tree_builder; }
+extern "C" int terra_amd_debug_shrink_reference_boxes ( HTerraScene h, float amount ) {
+    if ( ! ( amount >= 0.f ) ) return fail ( kTerraAmdErrBadArgument, "shrink amount must be >= 0" );
+    Scene* s = S ( h );
+    if ( s->test_shrink_reference_boxes != amount ) { s->test_shrink_reference_boxes = amount; s->dirty_objects = true; s->committed = false; }
+    return 0;
+}
 extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* out ) {
     Scene* s = S ( h );
     if ( !out ) return fail ( kTerraAmdErrBadArgument, "null output" );
@@ -332,6 +343,7 @@ extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* 
     out->tree_mode = s->tree_mode; out->fast_tree = s->use_fast ? 1 : 0; out->fast_tree_built_on_device = s->fast_on_device ? 1 : 0; out->leaf_cull = ( s->cull_ok && !s->use_fast ) ? 1 : 0;
     out->lds_resident = ( !s->use_fast && terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), s->dev.n_tris, s->max_stack ) ) ? 1 : 0;
     out->max_coordinate = s->coord_max; out->max_coordinate_allowed = TERRA_CULL_MAX_COORD;
+    out->last_call = s->last_call.load ( std::memory_order_relaxed ); out->camera_limit = ( s->reach || s->reach_cull ) ? s->reach_limit : TERRA_CULL_MAX_COORD;
     snprintf ( out->note, sizeof out->note, "%s", s->tree_note.c_str() );
     return 0;
 }
@@ -466,6 +478,55 @@ static bool verify_fast_tree ( const std::vector<DevNode>& nodes, const std::vec
     return true;
 }
 
+
+// ---- reachability tables (DevScene::ref_replay / fast_leaf_parent / fast_leaf_mask) -------------------------------------------------------------
+// nodes: the reference tree as the DEVICE holds it (breadth-first numbering, test hook applied); soup_of_fast[k] = soup index of fast triangle k.
+// Level L of fast triangle k = the L-th reference node on the way up from the triangle's leaf; its test is the slab test of the box that node's parent
+// stores for it. mask bit L is CLEAR when that test cannot fail for a ray that hits the triangle:
+//   (1) the box contains the triangle's extent with a clearance of `margin` (the containment argument at the scene's scale), or
+//   (2) L >= 1 and the box contains the box of level L - 1 component by component: for a regular ray (finite, non-zero inverse direction) fl((b - o) * inv) is
+//       monotone in b, so per axis the outer box's [near, far] contains the inner box's in the very same float arithmetic, hence tmin_outer <= tmin_inner,
+//       tmax_outer >= tmax_inner and "inner passes" implies "outer passes" exactly -- no error bound involved. Level L - 1 itself passes by induction (tested, or
+//       cleared). Irregular rays ignore the mask and replay every level (trace_device.h reference_reaches).
+struct ReachTables { std::vector<DevReplay> replay; std::vector<uint32_t> leaf_parent, leaf_mask; uint64_t levels = 0, replayed = 0; };
+static void build_reach_tables ( const std::vector<DevNode>& nodes, const std::vector<DevTri>& tris, const std::vector<uint32_t>& soup_of_fast, float margin, ReachTables& out ) {
+    const size_t nn = nodes.size(), nt = soup_of_fast.size();
+    out.replay.assign ( nn ? nn : 1, DevReplay{} );
+    std::vector<uint32_t> leaf_parent_of_soup ( tris.size(), 0u );
+    for ( size_t k = 0; k < nn; ++k ) for ( int c = 0; c < 2; ++c ) {
+        const uint32_t w = nodes[k].child[c];
+        if ( w == DEV_CHILD_EMPTY ) continue;
+        if ( w & DEV_CHILD_LEAF ) { leaf_parent_of_soup[w & 0x7fffffffu] = ( uint32_t ) k; continue; }
+        DevReplay& r = out.replay[w];
+        memcpy ( r.bmin, c ? nodes[k].min1 : nodes[k].min0, 12 ); memcpy ( r.bmax, c ? nodes[k].max1 : nodes[k].max0, 12 );
+        r.parent = ( uint32_t ) k; r.pad = 0;
+    }
+    // does node q's own box (the one its parent tests) contain the box of its child node w, component by component?  (false for NaN)
+    auto contains = [&] ( const DevReplay & outer, const DevReplay & inner ) {
+        bool ok = true;
+        for ( int a = 0; a < 3; ++a ) ok = ok && outer.bmin[a] <= inner.bmin[a] && outer.bmax[a] >= inner.bmax[a];
+        return ok;
+    };
+    out.leaf_parent.resize ( nt ); out.leaf_mask.resize ( nt );
+    for ( size_t k = 0; k < nt; ++k ) {
+        const uint32_t soup = soup_of_fast[k];
+        out.leaf_parent[k] = leaf_parent_of_soup[soup];
+        float lo[3], hi[3];
+        for ( int a = 0; a < 3; ++a ) { lo[a] = std::min ( tris[soup].a[a], std::min ( tris[soup].b[a], tris[soup].c[a] ) ); hi[a] = std::max ( tris[soup].a[a], std::max ( tris[soup].b[a], tris[soup].c[a] ) ); }
+        uint32_t mask = 0, level = 0, below = 0;
+        for ( uint32_t q = leaf_parent_of_soup[soup]; q != 0u; ++level ) {
+            const DevReplay& r = out.replay[q];
+            bool clear = true;
+            for ( int a = 0; a < 3; ++a ) clear = clear && ( lo[a] - r.bmin[a] >= margin ) && ( r.bmax[a] - hi[a] >= margin );      // (false for NaN)
+            if ( !clear && level > 0 ) clear = contains ( r, out.replay[below] );
+            if ( !clear ) { mask |= 1u << ( level < 31u ? level : 31u ); ++out.replayed; }
+            ++out.levels;
+            below = q; q = r.parent;
+        }
+        out.leaf_mask[k] = mask;
+    }
+}
+
 // validates that every material can run on the device and uploads the flattened scene
 static int upload_scene ( Scene* s ) {
     const size_t nobj = s->objects_pop;
@@ -581,15 +642,16 @@ static int upload_scene ( Scene* s ) {
     }
     // test hook (tests/test_gpu_render.py "reachability"): shrink the DEVICE copy of the reference tree's boxes, so that the reference traversal -- as the device replays
     // it -- misses triangles the watertight test would hit, the situation the reachability replay exists for and that float rounding alone produces too rarely to test
-    if ( const char* e = getenv ( "TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES" ) ) {
-        const float g = ( float ) atof ( e );
+    if ( s->test_shrink_reference_boxes > 0.f ) {
+        const float g = s->test_shrink_reference_boxes;
         for ( DevNode& d : nodes ) for ( int a = 0; a < 3; ++a ) {
             if ( d.max0[a] - d.min0[a] > 2.f * g ) { d.min0[a] += g; d.max0[a] -= g; }
             if ( d.max1[a] - d.min1[a] > 2.f * g ) { d.min1[a] += g; d.max1[a] -= g; }
         }
     }
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
-    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device, ref_parent, fast_leaf_parent, fast_leaf_mask;
+    std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device;
+    ReachTables reach_tabs;
     s->fast_nodes = 0; s->fast_max_stack = 1; s->fast_on_device = false;
     // traversal policy (see Scene::tree_mode and the containment check above)
     s->coord_max = 0.f; s->cull_ok = false; s->tree_note.clear();
@@ -598,11 +660,13 @@ static int upload_scene ( Scene* s ) {
     bool coords_finite = true;
     for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count * 9; ++i ) { float v = fabsf ( ( &s->objects[j].triangles[0].a.x ) [i] ); if ( v > s->coord_max ) s->coord_max = v; if ( !std::isfinite ( v ) ) coords_finite = false; }
     const bool resident = terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack );
+    const bool hooked = s->test_shrink_reference_boxes > 0.f;      // the containment proof below ran on the unshrunk boxes: no shortcut that rests on it
     bool auto_ok = false;
     if ( s->tree_mode == 2 ) {
         std::string why;
         if ( ntri < 2 ) s->tree_note = "fewer than 2 triangles: replica traversal";
         else if ( !margin_ok ) { char b[160]; snprintf ( b, sizeof b, "a vertex coordinate exceeds %.1f (largest %.6g): the 1e-4 box margin is not provably above rounding error, replica traversal", ( double ) TERRA_CULL_MAX_COORD, ( double ) s->coord_max ); s->tree_note = b; }
+        else if ( hooked ) s->tree_note = "TEST HOOK terra_amd_debug_shrink_reference_boxes: replica traversal";
         else if ( !verify_reference_leaf_boxes ( s, why ) ) s->tree_note = why + ": replica traversal";
         else auto_ok = true;
     } else s->tree_note = s->tree_mode == 0 ? "replica traversal requested" : "fast tree requested";
@@ -612,15 +676,39 @@ static int upload_scene ( Scene* s ) {
     // and a hit stands only if the reference traversal would have reached it (its inner ancestors' slab tests, replayed exactly: for the closest of all hits first, and only
     // if that one fails -- float rounding makes it very rare -- for every candidate of a second pass; trace_device.h bvh_traverse_fast). Rays may start
     // up to TERRA_REACH_CAMERA_FACTOR x the scene's largest coordinate from the origin (the camera, checked per call); margin = 128 u x that limit.
-    s->reach = false; s->reach_limit = 0.f;
+    // LDS-resident scenes out of range keep the reference tree and its exact traversal of the inner nodes; their LEAF boxes -- which the reference never tests -- are rebuilt
+    // around the triangle's extent with that same margin, so the leaf-box cull only skips triangle tests that cannot succeed: no replay needed (reach_cull).
+    s->reach = false; s->reach_cull = false; s->reach_limit = 0.f;
     float reach_margin = 0.f;
-    if ( s->tree_mode == 2 && !auto_ok && !margin_ok && ntri >= 2 && !resident && coords_finite && s->coord_max <= TERRA_REACH_MAX_COORD ) {
-        s->reach = true; s->reach_limit = TERRA_REACH_CAMERA_FACTOR * s->coord_max;
+    if ( s->tree_mode == 2 && !auto_ok && !margin_ok && ntri >= 2 && coords_finite && s->coord_max <= TERRA_REACH_MAX_COORD ) {
+        s->reach_limit = TERRA_REACH_CAMERA_FACTOR * s->coord_max;
         reach_margin = 128.f * 5.9604645e-8f * s->reach_limit;
-        char b[200]; snprintf ( b, sizeof b, "largest coordinate %.6g exceeds %.1f: fast tree with boxes inflated by %.3g, the reference's reachability replayed for the closest hit", ( double ) s->coord_max, ( double ) TERRA_CULL_MAX_COORD, ( double ) reach_margin );
+        char b[256];
+        if ( resident ) {
+            s->reach_cull = true; s->cull_ok = true;
+            snprintf ( b, sizeof b, "largest coordinate %.6g exceeds %.1f: reference tree with the leaf-box cull on leaf boxes rebuilt with a margin of %.3g (scene is LDS-resident)", ( double ) s->coord_max, ( double ) TERRA_CULL_MAX_COORD, ( double ) reach_margin );
+        } else {
+            s->reach = true;
+            snprintf ( b, sizeof b, "largest coordinate %.6g exceeds %.1f: fast tree with boxes inflated by %.3g, the reference's reachability replayed for the closest hit", ( double ) s->coord_max, ( double ) TERRA_CULL_MAX_COORD, ( double ) reach_margin );
+        }
         s->tree_note = b;
     }
+    if ( s->reach_cull ) {
+        // every leaf child's box := its triangle's extent +- the margin (united with the stored box): a ray that hits the triangle passes this box's slab test by the
+        // error bound above, at the scene's scale; inner boxes stay as they are (their tests ARE the reference's traversal)
+        for ( DevNode& d : nodes ) for ( int c = 0; c < 2; ++c ) {
+            if ( d.child[c] == DEV_CHILD_EMPTY || ! ( d.child[c] & DEV_CHILD_LEAF ) ) continue;
+            const DevTri& t = tris[d.child[c] & 0x7fffffffu];
+            float* mn = c ? d.min1 : d.min0; float* mx = c ? d.max1 : d.max0;
+            for ( int a = 0; a < 3; ++a ) {
+                const float lo = std::min ( t.a[a], std::min ( t.b[a], t.c[a] ) ) - reach_margin, hi = std::max ( t.a[a], std::max ( t.b[a], t.c[a] ) ) + reach_margin;
+                mn[a] = std::min ( mn[a], lo ); mx[a] = std::max ( mx[a], hi );
+            }
+        }
+    }
     s->use_fast = s->tree_mode == 1 || ( auto_ok && !resident ) || s->reach;
+    const float fast_extra = ( s->reach && reach_margin > 1e-4f ) ? reach_margin - 1e-4f : 0.f;      // on top of the +-1e-4 of every triangle box
+    std::vector<uint32_t> soup_of_fast;                                                             // reach: soup index of every fast triangle (host-built: known here)
     if ( s->use_fast ) {
         // rank of every soup triangle in the reference traversal's leaf visit order (all boxes hit)
         std::vector<uint32_t> rank ( ntri ? ntri : 1, 0 );
@@ -634,7 +722,7 @@ static int upload_scene ( Scene* s ) {
                 }
             }
         }
-        s->fast_on_device = s->tree_builder == 1 && ntri > 64 && terra_amd_device_count() > 0 && !s->reach;      // (the inflated boxes of the reachability mode are the host builder's)
+        s->fast_on_device = s->tree_builder == 1 && ntri > 64 && terra_amd_device_count() > 0;
         if ( s->fast_on_device ) {
             // built after the upload, from the soup already in HBM; the host only supplies the reference visit ranks
             rank_for_device.swap ( rank );
@@ -643,7 +731,7 @@ static int upload_scene ( Scene* s ) {
             for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count; ++i ) {
                 fastbvh::Prim& q = prims[s->first_tri[j] + i];
                 q.box = bvh::empty_box(); bvh::grow_by_triangle ( q.box, s->objects[j].triangles[i] );
-                if ( s->reach && reach_margin > 1e-4f ) { const float g = reach_margin - 1e-4f; q.box.min.x -= g; q.box.min.y -= g; q.box.min.z -= g; q.box.max.x += g; q.box.max.y += g; q.box.max.z += g; }
+                if ( fast_extra > 0.f ) { const float g = fast_extra; q.box.min.x -= g; q.box.min.y -= g; q.box.min.z -= g; q.box.max.x += g; q.box.max.y += g; q.box.max.z += g; }
                 q.c[0] = 0.5f * ( q.box.min.x + q.box.max.x ); q.c[1] = 0.5f * ( q.box.min.y + q.box.max.y ); q.c[2] = 0.5f * ( q.box.min.z + q.box.max.z );
                 q.soup = ( uint32_t ) ( s->first_tri[j] + i );
             }
@@ -661,38 +749,20 @@ static int upload_scene ( Scene* s ) {
             fnodes.swap ( built.nodes );
             ftris.resize ( ntri ? ntri : 1 );
             for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
-            if ( s->reach ) {          // parent links of the reference tree (device numbering) and, per fast triangle, the reference node it hangs from
-                ref_parent.assign ( nodes.size(), 0u ); std::vector<uint32_t> leaf_parent ( ntri, 0u );
-                for ( size_t k = 0; k < nodes.size(); ++k ) for ( int c = 0; c < 2; ++c ) {
-                    const uint32_t w = nodes[k].child[c];
-                    if ( w == DEV_CHILD_EMPTY ) continue;
-                    if ( w & DEV_CHILD_LEAF ) leaf_parent[w & 0x7fffffffu] = ( uint32_t ) k; else ref_parent[w] = ( uint32_t ) ( k << 1 ) | ( uint32_t ) c;
-                }
-                fast_leaf_parent.resize ( ntri ); fast_leaf_mask.resize ( ntri );
-                for ( size_t k = 0; k < built.order.size(); ++k ) {
-                    const uint32_t soup = built.order[k];
-                    fast_leaf_parent[k] = leaf_parent[soup];
-                    // which ancestors' slab tests can fail at all for a ray that hits this triangle: those whose box does not clear the triangle's extent by the margin
-                    // (the boxes as the DEVICE holds them: what the replay tests)
-                    float lo[3], hi[3];
-                    for ( int a = 0; a < 3; ++a ) { lo[a] = std::min ( tris[soup].a[a], std::min ( tris[soup].b[a], tris[soup].c[a] ) ); hi[a] = std::max ( tris[soup].a[a], std::max ( tris[soup].b[a], tris[soup].c[a] ) ); }
-                    uint32_t mask = 0, level = 0;
-                    for ( uint32_t q = leaf_parent[soup]; q != 0u; ++level ) {
-                        const uint32_t pw = ref_parent[q], par = pw >> 1;
-                        const float* mn = ( pw & 1u ) ? nodes[par].min1 : nodes[par].min0; const float* mx = ( pw & 1u ) ? nodes[par].max1 : nodes[par].max0;
-                        bool clear = true;
-                        for ( int a = 0; a < 3; ++a ) clear = clear && ( lo[a] - mn[a] >= reach_margin ) && ( mx[a] - hi[a] >= reach_margin );      // (false for NaN)
-                        if ( !clear ) mask |= 1u << ( level < 31u ? level : 31u );
-                        q = par;
-                    }
-                    fast_leaf_mask[k] = mask;
-                }
-            }
+            if ( s->reach && s->use_fast ) soup_of_fast = built.order;
             s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
         }
     }
     if ( s->tree_mode == 2 && s->reach && !s->use_fast ) { s->reach = false; }
-    if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
+    // the stack of a fast-tree launch is one KB of LDS per entry and block (terra_plan_fast_tree): a tree too deep for the LDS a block may ask for (clustered or
+    // coincident geometry under the device builder's Morton order can reach ~60 levels) cannot launch -- such a scene keeps the reference tree, which always fits
+    auto fast_stack_fits = [] ( int depth ) { return ( size_t ) ( depth + TERRA_FAST_STACK_AUX_KB ) * 1024 + 64 * 64 <= ( size_t ) TERRA_FAST_STACK_LDS_LIMIT; };
+    if ( s->use_fast && !s->fast_on_device && !fast_stack_fits ( s->fast_max_stack ) ) {
+        char b[160]; snprintf ( b, sizeof b, "fast tree needs a traversal stack of %d entries, more LDS than a block may hold: reference tree, replica traversal", s->fast_max_stack );
+        s->use_fast = false; s->reach = false; s->tree_note = b; fnodes.clear(); ftris.clear(); soup_of_fast.clear(); s->fast_nodes = 0; s->fast_max_stack = 1;
+    }
+    if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : ( resident ? "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)" : s->tree_note );
+    if ( s->reach && !s->fast_on_device ) build_reach_tables ( nodes, tris, soup_of_fast, reach_margin, reach_tabs );
     // one blob, 256-byte aligned sections
     auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
@@ -700,7 +770,8 @@ static int upload_scene ( Scene* s ) {
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
     const size_t fn_cap = s->fast_on_device ? ntri : fnodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();      // a device build writes at most n - 1 nodes, n triangles
     size_t o_ft = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );
-    const size_t o_rp = o_td, o_lp = align ( o_rp + ref_parent.size() * 4 ), o_lm = align ( o_lp + fast_leaf_parent.size() * 4 ); o_td = align ( o_lm + fast_leaf_mask.size() * 4 );
+    const size_t n_replay = s->reach ? ( nodes.size() ? nodes.size() : 1 ) : 0, n_reach_tri = s->reach ? ntri : 0;
+    const size_t o_rp = o_td, o_lp = align ( o_rp + n_replay * sizeof ( DevReplay ) ), o_lm = align ( o_lp + n_reach_tri * 4 ); o_td = align ( o_lm + n_reach_tri * 4 );
     std::vector<DevTexture> tdesc ( textures.size() );
     std::vector<size_t> tex_off ( textures.size() );
     size_t total = align ( o_td + tdesc.size() * sizeof ( DevTexture ) );
@@ -729,11 +800,14 @@ static int upload_scene ( Scene* s ) {
         HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
-    if ( !ref_parent.empty() ) {
-        HIP_TRY ( hipMemcpy ( base + o_rp, ref_parent.data(), ref_parent.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
-        HIP_TRY ( hipMemcpy ( base + o_lp, fast_leaf_parent.data(), fast_leaf_parent.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
-        HIP_TRY ( hipMemcpy ( base + o_lm, fast_leaf_mask.data(), fast_leaf_mask.size() * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
-    }
+    auto upload_reach_tables = [&] () -> int {
+        HIP_TRY ( hipMemcpy ( base + o_rp, reach_tabs.replay.data(), n_replay * sizeof ( DevReplay ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemcpy ( base + o_lp, reach_tabs.leaf_parent.data(), n_reach_tri * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemcpy ( base + o_lm, reach_tabs.leaf_mask.data(), n_reach_tri * 4, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        if ( timing_on() ) fprintf ( stderr, "[terra_amd timing]   reachability: %llu ancestor levels, %llu to replay (%.2f per triangle)\n", ( unsigned long long ) reach_tabs.levels, ( unsigned long long ) reach_tabs.replayed, ntri ? ( double ) reach_tabs.replayed / ( double ) ntri : 0. );
+        return 0;
+    };
+    if ( s->reach && !s->fast_on_device ) { if ( int rc = upload_reach_tables() ) return rc; }
     bool have_fast = !fnodes.empty();
     if ( s->fast_on_device ) {
         double t_phase = now_s();
@@ -741,12 +815,16 @@ static int upload_scene ( Scene* s ) {
         HIP_TRY ( hipMalloc ( ( void** ) &d_rank, ntri * sizeof ( uint32_t ) ), kTerraAmdErrNoDevice );
         hipError_t e = hipMemcpy ( d_rank, rank_for_device.data(), ntri * sizeof ( uint32_t ), hipMemcpyHostToDevice );
         uint32_t built_nodes = 0; int built_stack = 1;
-        if ( e == hipSuccess ) e = terra_build_fast_tree_device ( ( const DevTri* ) ( base + o_tris ), d_rank, ( uint32_t ) ntri, ( DevNode* ) ( base + o_fn ), ( DevTri* ) ( base + o_ft ), &built_nodes, &built_stack, nullptr );
+        if ( e == hipSuccess ) e = terra_build_fast_tree_device ( ( const DevTri* ) ( base + o_tris ), d_rank, ( uint32_t ) ntri, fast_extra, ( DevNode* ) ( base + o_fn ), ( DevTri* ) ( base + o_ft ), &built_nodes, &built_stack, nullptr );
         ( void ) hipFree ( d_rank );
         if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "device tree build: %s", hipGetErrorString ( e ) );
         phase ( "fast tree (device LBVH)", t_phase );
         s->fast_nodes = built_nodes; s->fast_max_stack = built_stack; have_fast = true;
-        if ( s->tree_mode == 2 || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {          // the culling relies on containment: read the tree back and check it like the host-built one
+        if ( !fast_stack_fits ( built_stack ) ) {          // (a Morton-ordered tree over clustered or coincident geometry can be ~60 levels deep)
+            char b[200]; snprintf ( b, sizeof b, "device-built fast tree needs a traversal stack of %d entries, more LDS than a block may hold: reference tree, replica traversal", built_stack );
+            s->use_fast = false; s->reach = false; s->fast_on_device = false; s->tree_note = b; s->fast_nodes = 0; s->fast_max_stack = 1; have_fast = false;
+            if ( s->tree_mode == 2 && auto_ok && resident ) s->tree_note = "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
+        } else if ( s->tree_mode == 2 || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {          // the culling relies on containment: read the tree back and check it like the host-built one
             std::vector<DevNode> rn ( built_nodes ); std::vector<DevTri> rt ( ntri );
             HIP_TRY ( hipMemcpy ( rn.data(), base + o_fn, rn.size() * sizeof ( DevNode ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
             HIP_TRY ( hipMemcpy ( rt.data(), base + o_ft, rt.size() * sizeof ( DevTri ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
@@ -754,10 +832,18 @@ static int upload_scene ( Scene* s ) {
             for ( size_t k = 0; k < ntri; ++k ) {
                 TerraTriangle t; memcpy ( &t.a, rt[k].a, 12 ); memcpy ( &t.b, rt[k].b, 12 ); memcpy ( &t.c, rt[k].c, 12 );
                 leaf_boxes[k] = bvh::empty_box(); bvh::grow_by_triangle ( leaf_boxes[k], t );
+                if ( fast_extra > 0.f ) { const float g = fast_extra; TerraAABB& q = leaf_boxes[k]; q.min.x -= g; q.min.y -= g; q.min.z -= g; q.max.x += g; q.max.y += g; q.max.z += g; }
             }
             std::string why;
             if ( !verify_fast_tree ( rn, leaf_boxes, why ) ) return fail ( kTerraAmdErrLaunch, "device tree build: %s", why.c_str() );
             phase ( "  read back + containment check", t_phase );
+            if ( s->reach ) {          // the replay tables need the order the device put the triangles in
+                soup_of_fast.resize ( ntri );
+                for ( size_t k = 0; k < ntri; ++k ) soup_of_fast[k] = s->first_tri[rt[k].object] + rt[k].tri_in_object;
+                build_reach_tables ( nodes, tris, soup_of_fast, reach_margin, reach_tabs );
+                if ( int rc = upload_reach_tables() ) return rc;
+                phase ( "  reachability tables", t_phase );
+            }
         }
     }
     if ( have_fast && s->fast_nodes ) {       // boxes as (centre, half extent): what the kernels traverse; everything above checked the (min, max) form
@@ -779,8 +865,8 @@ static int upload_scene ( Scene* s ) {
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
     s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
-    s->dev.reach = ( s->reach && have_fast && !ref_parent.empty() ) ? 1u : 0u;
-    s->dev.ref_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
+    s->dev.reach = ( s->reach && have_fast && !reach_tabs.leaf_parent.empty() ) ? 1u : 0u;
+    s->dev.ref_replay = s->dev.reach ? ( const DevReplay* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
     s->device_ok = true;
     return 0;
@@ -915,7 +1001,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.tile_size = ( uint32_t ) tile; p.rank = ( uint32_t ) rank; p.world = ( uint32_t ) world;
     p.st_x = 0; p.st_y = 0; p.st_pitch = ( uint32_t ) fb_w;          // framebuffer arrays indexed like the frame (render_host stages a rectangle instead)
     p.spp = effective_spp ( s->opts );
-    p.split = 1; p.split_log2 = 0; p.chunk_spp = p.spp; p.partials = nullptr;
+    p.split = 1; p.split_log2 = 0; p.chunk_spp = p.spp; p.partials = nullptr; p.job_blocks = 0; p.job_queue = nullptr;
     p.bounces = ( uint32_t ) s->opts.bounces;
     p.integrator = ( int32_t ) s->opts.integrator; p.tonemap = ( int32_t ) s->opts.tonemapping_operator;
     if ( p.integrator < 0 || p.integrator > 6 ) return fail ( kTerraAmdErrBadArgument, "unknown integrator %d", p.integrator );
@@ -925,12 +1011,14 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.counters = s->d_counters;
     terra_plan_lds ( p );
     // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
-    const bool cam_ok = s->reach ? ( fabsf ( p.cam_pos[0] ) <= s->reach_limit && fabsf ( p.cam_pos[1] ) <= s->reach_limit && fabsf ( p.cam_pos[2] ) <= s->reach_limit ) : coords_within_margin ( p.cam_pos, 3 );
+    const bool cam_ok = ( s->reach || s->reach_cull ) ? ( fabsf ( p.cam_pos[0] ) <= s->reach_limit && fabsf ( p.cam_pos[1] ) <= s->reach_limit && fabsf ( p.cam_pos[2] ) <= s->reach_limit ) : coords_within_margin ( p.cam_pos, 3 );
     if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) {
         terra_plan_fast_tree ( p );
         if ( s->fast_on_device ) p.lds_nodes = 0;      // the device-built tree is not numbered top-levels-first: nothing worth staging
     }
     p.leaf_cull = ( s->cull_ok && cam_ok && p.lds_mode != 2 ) ? 1u : 0u;
+    // what this call runs (TerraAmdTraversalInfo::last_call): the commit-time decision can be overridden per call by the camera position
+    s->last_call.store ( p.lds_mode == 2 ? ( s->dev.reach ? kTerraAmdCallFastTreeReach : kTerraAmdCallFastTree ) : ( p.leaf_cull ? kTerraAmdCallLeafCull : kTerraAmdCallReplica ), std::memory_order_relaxed );
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;
     p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;
@@ -953,32 +1041,44 @@ static void account_launch ( Scene* s, const DevRenderParams& p ) {
     s->launches.fetch_add ( 1, std::memory_order_relaxed ); s->stat_pixels.fetch_add ( px, std::memory_order_relaxed ); s->stat_samples.fetch_add ( px * p.spp, std::memory_order_relaxed );
 }
 
-// One render of p on `stream`: a single kernel, or -- with a sample split -- the chunk kernel into a
-// stream-ordered scratch buffer followed by the resolve kernel (DevRenderParams::split).
+// One render of p on `stream`: the render kernel sums every (pixel, chunk) job into a stream-ordered scratch buffer (persistent grid,
+// jobs handed out through a queue word at the head of that buffer; render_kernels.hip "jobs"), then the resolve kernel folds the chunk
+// sums into the pixels in chunk order and tonemaps (DevRenderParams::split; split == 1: one chunk per pixel).
 static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
     uint32_t split = s->sample_split;
+    const uint32_t blocks = terra_render_blocks ( p );
+    if ( blocks == 0 ) return 0;
     if ( split == 0 ) {
         // automatic: enough blocks to fill the GPU about twice (256 CUs x 5 resident blocks), chunks of at least 16 samples.
         // Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
-        const uint32_t blocks = terra_render_blocks ( p );
         split = 1;
         while ( split < 16 && blocks * split < 2560 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
     }
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
-    if ( split <= 1 ) { HIP_TRY ( terra_launch_render ( p, stream ), kTerraAmdErrLaunch ); return 0; }
-    const uint32_t blocks = terra_render_blocks ( p );
-    if ( blocks == 0 ) return 0;
+    if ( split < 1 ) split = 1;
     static thread_local int pool_device = -1;
     if ( pool_device != s->device ) {        // keep freed scratch cached in the device's default pool instead of returning it to the OS at every sync
         hipMemPool_t pool;
         if ( hipDeviceGetDefaultMemPool ( &pool, s->device ) == hipSuccess ) { uint64_t keep = ~0ull; ( void ) hipMemPoolSetAttribute ( pool, hipMemPoolAttrReleaseThreshold, &keep ); }
         pool_device = s->device;
     }
+    const size_t header = 256;                                     // the job queue word (+ padding that keeps the partials 256-byte aligned)
     void* scratch = nullptr;
-    HIP_TRY ( hipMallocAsync ( &scratch, ( size_t ) split * blocks * 256 * sizeof ( float4 ), stream ), kTerraAmdErrNoDevice );
+    HIP_TRY ( hipMallocAsync ( &scratch, header + ( size_t ) split * blocks * 256 * sizeof ( float4 ), stream ), kTerraAmdErrNoDevice );
+    hipError_t e = hipMemsetAsync ( scratch, 0, header, stream );
     p.split = split; p.split_log2 = 0; while ( ( 1u << p.split_log2 ) < split ) ++p.split_log2;
-    p.chunk_spp = p.spp / split; p.partials = ( float4* ) scratch;
-    hipError_t e = terra_launch_render ( p, stream );
+    p.chunk_spp = p.spp / split; p.partials = ( float4* ) ( ( char* ) scratch + header );
+    p.job_blocks = blocks * split; p.job_queue = ( uint32_t* ) scratch;
+    {   // the job decode divides block numbers by launch constants: as multiplications by ceil(2^32 / d), exact while (largest dividend) * divisor < 2^32
+        const uint64_t bpt = p.tile_size / 16, bpt2 = bpt * bpt, tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size, tiles_y = ( p.h + p.tile_size - 1 ) / p.tile_size;
+        auto magic = [] ( uint64_t d ) { return d <= 1 ? 0u : ( uint32_t ) ( ( ( 1ull << 32 ) + d - 1 ) / d ); };
+        if ( ! ( ( uint64_t ) blocks * split * 256 < ( 1ull << 32 ) && ( uint64_t ) blocks * bpt2 < ( 1ull << 32 ) && ( tiles_x * tiles_y + p.world ) * tiles_x < ( 1ull << 32 ) && bpt2 * bpt < ( 1ull << 32 ) ) ) {
+            ( void ) hipFreeAsync ( scratch, stream );
+            return fail ( kTerraAmdErrBadArgument, "render rectangle too large for one launch (%u blocks x split %u): render it in several calls", blocks, split );
+        }
+        p.job_div_bpt2 = magic ( bpt2 ); p.job_div_tiles_x = magic ( tiles_x ); p.job_div_bpt = magic ( bpt ); p.job_tiles_x = ( uint32_t ) tiles_x;
+    }
+    if ( e == hipSuccess ) e = terra_launch_render ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_resolve ( p, stream );
     ( void ) hipFreeAsync ( scratch, stream );
     if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "render launch: %s", hipGetErrorString ( e ) );

@@ -150,7 +150,7 @@ TD RayState ray_state_init ( const Ray& r ) {
     int iy = ix + 1 == 3 ? 0 : ix + 1;
     if ( pick ( r.d, iz ) < 0.f ) { int t = ix; ix = iy; iy = t; }
     RayState s;
-    s.scalez = 1.f / pick ( r.d, iz );
+    s.scalez = pick ( r.inv, iz );          // 1.f / d[iz] (src/TerraGeometry.c:124): the quotient make_ray already holds, same operands, same rounding
     s.shearx = pick ( r.d, ix ) * s.scalez;
     s.sheary = pick ( r.d, iy ) * s.scalez;
     s.ix = ix; s.iy = iy; s.iz = iz;
@@ -472,21 +472,21 @@ struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
 #define TERRA_REACH_SELFCHECK 0
 #endif
 TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
-    const float4* rn = reinterpret_cast<const float4*> ( T.sc.nodes );
-    uint32_t mask = T.sc.fast_leaf_mask[ti];                 // levels whose test can fail at all (DevScene::fast_leaf_mask); the walk ends above the highest of them
+    const float4* tab = reinterpret_cast<const float4*> ( T.sc.ref_replay );
+    // levels whose test can fail at all (DevScene::fast_leaf_mask): the walk ends above the highest of them. The mask's "contains the level below" shortcut
+    // needs a regular ray (monotone slab arithmetic, no NaN); any other ray replays every level
+    uint32_t mask = ray_is_regular ( ray ) ? T.sc.fast_leaf_mask[ti] : 0xffffffffu;
     uint32_t q = T.sc.fast_leaf_parent[ti];
     bool ok = true;
     while ( q != 0u && ( TERRA_REACH_SELFCHECK || mask != 0u ) ) {
-        const uint32_t pw = T.sc.ref_parent[q], par = pw >> 1;
+        const float4 a = tab[2 * q], b = tab[2 * q + 1];          // {min, parent} {max, -}
         if ( TERRA_REACH_SELFCHECK || ( mask & 1u ) ) {
-            const float4 a = rn[4 * par], b = rn[4 * par + 1], c4 = rn[4 * par + 2];
-            const V3 mn = ( pw & 1u ) ? v3 ( b.z, b.w, c4.x ) : v3 ( a.x, a.y, a.z ), mx = ( pw & 1u ) ? v3 ( c4.y, c4.z, c4.w ) : v3 ( a.w, b.x, b.y );
-            if ( !slab<false> ( mn, mx, ray ) ) {
+            if ( !slab<false> ( v3 ( a.x, a.y, a.z ), v3 ( b.x, b.y, b.z ), ray ) ) {
                 if ( !TERRA_REACH_SELFCHECK ) return false;
                 if ( mask & 1u ) ok = false; else if ( T.faults ) atomicAdd ( T.faults, 1ull );      // a cleared level failed: the mask is wrong
             }
         }
-        q = par;
+        q = __float_as_uint ( a.w );
         mask = ( mask & 0x80000000u ) | ( mask >> 1 );      // next level (bit 31 stands for every level from 31 up)
     }
     return ok;

@@ -24,23 +24,23 @@
 namespace {
 struct Box { float mn[3], mx[3]; };
 
-__device__ __forceinline__ Box tri_box ( const DevTri& t ) {          // bvh::grow_by_triangle (tree_build.cpp): extent grown by 1e-4, the add in double
+__device__ __forceinline__ Box tri_box ( const DevTri& t, float extra ) {          // bvh::grow_by_triangle (tree_build.cpp): extent grown by 1e-4, the add in double; `extra` more on every side (reachability mode, scene_host.cpp)
     Box b;
     const float* a = t.a; const float* bb = t.b; const float* c = t.c;
     #pragma unroll
     for ( int k = 0; k < 3; ++k ) {
         const float lo = fminf ( a[k], fminf ( bb[k], c[k] ) ), hi = fmaxf ( a[k], fmaxf ( bb[k], c[k] ) );
-        b.mn[k] = ( float ) ( ( double ) lo - 1e-4 ); b.mx[k] = ( float ) ( ( double ) hi + 1e-4 );
+        b.mn[k] = ( float ) ( ( double ) lo - 1e-4 ) - extra; b.mx[k] = ( float ) ( ( double ) hi + 1e-4 ) + extra;
     }
     return b;
 }
 __device__ __forceinline__ uint32_t ordered ( float f ) { uint32_t u = __float_as_uint ( f ); return ( u & 0x80000000u ) ? ~u : ( u | 0x80000000u ); }     // monotone float -> uint
 __device__ __forceinline__ float unordered ( uint32_t u ) { return __uint_as_float ( ( u & 0x80000000u ) ? ( u & 0x7fffffffu ) : ~u ); }
 
-__global__ void k_boxes ( const DevTri* tris, uint32_t n, Box* boxes, uint32_t* bounds6 ) {
+__global__ void k_boxes ( const DevTri* tris, uint32_t n, float extra, Box* boxes, uint32_t* bounds6 ) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if ( i >= n ) return;
-    Box b = tri_box ( tris[i] );
+    Box b = tri_box ( tris[i], extra );
     boxes[i] = b;
     #pragma unroll
     for ( int k = 0; k < 3; ++k ) {          // bounds of the box CENTRES (what the Morton grid spans)
@@ -163,7 +163,7 @@ struct Scratch {
 #define TB_TRY(expr) do { hipError_t e_ = ( expr ); if ( e_ != hipSuccess ) return e_; } while ( 0 )
 
 // tris / rank / out_nodes (capacity n - 1) / out_tris (capacity n) are device pointers; n > TERRA_LBVH_LEAF_MAX.
-hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream ) {
+hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, float extra_margin, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream ) {
     if ( n <= TERRA_LBVH_LEAF_MAX || n > 0x07ffffffu ) return hipErrorInvalidValue;
     const size_t N = n;
     auto al = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
@@ -197,7 +197,7 @@ hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* ra
     TB_TRY ( hipMemsetAsync ( arrived, 0, N * 4, stream ) );
     TB_TRY ( hipMemsetAsync ( keep, 0, N * 4, stream ) );
     const dim3 blk ( 256 ), grd ( ( n + 255 ) / 256 );
-    hipLaunchKernelGGL ( k_boxes, grd, blk, 0, stream, tris, n, boxes, misc );
+    hipLaunchKernelGGL ( k_boxes, grd, blk, 0, stream, tris, n, extra_margin, boxes, misc );
     hipLaunchKernelGGL ( k_keys, grd, blk, 0, stream, boxes, n, misc, keys0 );
     TB_TRY ( hipcub::DeviceRadixSort::SortKeys ( base + o_tmp, sort_bytes, keys0, keys, ( int ) n, 0, 62, stream ) );
     hipLaunchKernelGGL ( k_hierarchy, grd, blk, 0, stream, keys, ( int ) n, child, range, pin, plf );

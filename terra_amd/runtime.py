@@ -36,7 +36,11 @@ class Stats(C.Structure):
 
 
 class TraversalInfo(C.Structure):
-    _fields_ = [("tree_mode", C.c_int), ("fast_tree", C.c_int), ("fast_tree_built_on_device", C.c_int), ("leaf_cull", C.c_int), ("lds_resident", C.c_int), ("max_coordinate", C.c_float), ("max_coordinate_allowed", C.c_float), ("note", C.c_char * 192)]
+    _fields_ = [("tree_mode", C.c_int), ("fast_tree", C.c_int), ("fast_tree_built_on_device", C.c_int), ("leaf_cull", C.c_int), ("lds_resident", C.c_int), ("max_coordinate", C.c_float), ("max_coordinate_allowed", C.c_float), ("note", C.c_char * 256),
+                ("last_call", C.c_int), ("camera_limit", C.c_float)]
+
+
+CALL_TRAVERSAL = {0: "none", 1: "reference tree, replica traversal", 2: "reference tree + leaf-box cull", 3: "fast tree", 4: "fast tree + reachability replay"}
 
 
 class SceneInfo(C.Structure):
@@ -56,6 +60,7 @@ _EXTRA = {
     "terra_amd_set_device": (C.c_int, [C.c_int]),
     "terra_amd_get_device": (C.c_int, []),
     "terra_amd_set_frame_seed": (None, [C.c_void_p, C.c_uint64]),
+    "terra_amd_debug_shrink_reference_boxes": (C.c_int, [C.c_void_p, C.c_float]),
     "terra_amd_get_frame_seed": (C.c_uint64, [C.c_void_p]),
     "terra_amd_set_tree_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_tree_mode": (C.c_int, [C.c_void_p]),
@@ -163,23 +168,30 @@ def packed_floats_per_rank(width: int, height: int, tile: int, world: int) -> in
     return most * tile * tile * 7
 
 
-def gather_frame(fb_pack, fb_unpack, width, height, tile, rank, world, dist, make_buffer, dst=0):
+def gather_frame(fb_pack, fb_unpack, width, height, tile, rank, world, dist, make_buffer, dst=0, mark=None):
     """One gather of every rank's packed tiles to `dst`, then unpack there.
 
     fb_pack(rank) -> 1-D float32 tensor holding this rank's tiles in the packed layout
     fb_unpack(src_rank, packed) writes rank src_rank's tiles into the destination frame (called on dst only)
     dist: torch.distributed (backend nccl == RCCL on the GPU box, gloo in CPU tests)
+    mark(name): optional, called after each phase is QUEUED ("packed", "gathered", "unpacked") -- bench.py records stream events there
     """
+    mark = mark or (lambda name: None)
     mine = fb_pack(rank)
+    mark("packed")
     if world == 1:
+        mark("gathered"); mark("unpacked")
         return
     n = packed_floats_per_rank(width, height, tile, world)
     assert mine.numel() == n
     if rank == dst:
         bufs = [make_buffer(n) for _ in range(world)]
         dist.gather(mine, gather_list=bufs, dst=dst)
+        mark("gathered")
         for src in range(world):
             if src != dst:
                 fb_unpack(src, bufs[src])
     else:
         dist.gather(mine, gather_list=None, dst=dst)
+        mark("gathered")
+    mark("unpacked")

@@ -23,26 +23,37 @@ def test_launcher_command_is_the_drivers_contract():
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
 
 
-def _run_with_child(monkeypatch, capsys, child_source, tmp_path):
+def _run_with_child(monkeypatch, capfd, child_source, tmp_path):
     import bench
     prog = tmp_path / "child.py"; prog.write_text(child_source)
     monkeypatch.setattr(bench, "launcher_command", lambda args, argv, port: [sys.executable, str(prog)] + list(argv))
     args = bench.parse_args(["--gpus", "2"])
     rc = bench.self_launch(args, ["--gpus", "2"])
-    return rc, capsys.readouterr()
+    return rc, capfd.readouterr()
 
 
-def test_self_launch_relays_the_result_line(monkeypatch, capsys, tmp_path):
+def test_self_launch_relays_the_result_line(monkeypatch, capfd, tmp_path):
     line = json.dumps({"metric": "Msamples/s", "value": 1.0, "n_gpus": 2})
-    rc, io = _run_with_child(monkeypatch, capsys, f"import sys\nprint('noise from a rank')\nprint({line!r})\nprint('more noise')\n", tmp_path)
+    rc, io = _run_with_child(monkeypatch, capfd, f"import sys\nprint('noise from a rank')\nprint({line!r})\nprint('more noise')\n", tmp_path)
     assert rc == 0 and io.out.strip() == line
 
 
-def test_self_launch_fails_loudly(monkeypatch, capsys, tmp_path):
-    rc, io = _run_with_child(monkeypatch, capsys, "import sys\nsys.stderr.write('rank 1 died\\n')\nsys.exit(3)\n", tmp_path)
+def test_self_launch_fails_loudly(monkeypatch, capfd, tmp_path):
+    rc, io = _run_with_child(monkeypatch, capfd, "import sys\nsys.stderr.write('rank 1 died\\n')\nsys.exit(3)\n", tmp_path)
     assert rc == 3 and io.out == "" and "rank 1 died" in io.err and "exited with code 3" in io.err
-    rc, io = _run_with_child(monkeypatch, capsys, "print('no json here')\n", tmp_path)
+    rc, io = _run_with_child(monkeypatch, capfd, "print('no json here')\n", tmp_path)
     assert rc == 1 and "printed no result line" in io.err
+
+
+def test_self_launch_kills_a_hung_child_after_the_timeout(monkeypatch, capfd, tmp_path):
+    """a rank stuck in the rendezvous must not hang the parent (and its whole process group goes with it)"""
+    import bench, time
+    prog = tmp_path / "child.py"; prog.write_text("import time\nprint('started', flush=True)\ntime.sleep(600)\n")
+    monkeypatch.setattr(bench, "launcher_command", lambda args, argv, port: [sys.executable, str(prog)] + list(argv))
+    args = bench.parse_args(["--gpus", "2", "--launch-timeout", "1.5"])
+    t = time.time(); rc = bench.self_launch(args, ["--gpus", "2"]); dt = time.time() - t
+    io = capfd.readouterr()
+    assert rc == 124 and dt < 20 and "did not finish within" in io.err and io.out == ""
 
 
 def test_bare_invocation_with_gpus_gt_1_never_touches_the_gpu_in_the_parent(tmp_path):

@@ -441,9 +441,9 @@ def test_reachability_mode_outside_the_coordinate_range(H, L, monkeypatch):
     import torch
     from tools.scaled_hall import scaled
 
-    def render(mode, integ):
+    def render(mode, integ, shrink=None, builder=None):
         d = scaled(scenes.sponza_hall(160, 90, 2, integrator=integ), 100.0)
-        L.clear_error(); s = scenes.build_scene(L, d, tree_mode=mode)
+        L.clear_error(); s = scenes.build_scene(L, d, tree_mode=mode, debug_shrink=shrink, tree_builder=builder)
         assert runtime.last_error() == "", runtime.last_error()
         ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(s, C.byref(ti)))
         fb = runtime.DeviceFramebuffer(d.width, d.height)
@@ -453,30 +453,66 @@ def test_reachability_mode_outside_the_coordinate_range(H, L, monkeypatch):
         return out
 
     # the compiled reference's own image of the scaled hall (tests/golden/render_hall_x100.npz)
-    monkeypatch.delenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", raising=False)
     g = G(H, "render_hall_x100")
     for integ, (w, h, spp) in {0: (160, 90, 2), 1: (64, 36, 1)}.items():
         out = render_dev(L, scaled(scenes.sponza_hall(w, h, spp, integrator=integ), 100.0), calls=True)
         assert H.same_bits(out["pixels"], g[f"i{integ}_pixels"]) and np.array_equal(out["rand_calls"], g[f"i{integ}_calls"].astype(np.uint32)), integ
-    for shrink in (None, "3.0"):
-        if shrink is None: monkeypatch.delenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", raising=False)
-        else: monkeypatch.setenv("TERRA_AMD_TEST_SHRINK_REFERENCE_BOXES", shrink)
+    for shrink in (None, 3.0):
         for integ in (0, 1):
-            ref = render(0, integ); auto = render(2, integ)
-            assert auto[2] == 1 and "reachability" in auto[3], auto[3]
-            assert same(H, ref[0], auto[0]) and same(H, ref[1], auto[1]), (shrink, integ)
+            ref = render(0, integ, shrink)
+            for builder in (0, 1):          # host binned SAH, device LBVH (its boxes inflated on the device, the replay tables made from the read-back)
+                auto = render(2, integ, shrink, builder)
+                assert auto[2] == 1 and "reachability" in auto[3], auto[3]
+                assert same(H, ref[0], auto[0]) and same(H, ref[1], auto[1]), (shrink, integ, builder)
         if shrink is not None:
-            plain = render(1, 0); ref = render(0, 0)
+            plain = render(1, 0, shrink); ref = render(0, 0, shrink)
             assert not same(H, plain[1], ref[1])          # the hook bites: without the replay the fast tree finds hits the (shrunk) reference misses
         # ... and ray by ray: the fast tree with the replay against the reference tree's own traversal
         d = scaled(scenes.sponza_hall(64, 36, 1), 100.0)
-        s = scenes.build_scene(L, d, tree_mode=2)
+        s = scenes.build_scene(L, d, tree_mode=2, debug_shrink=shrink)
         o, dd = H.scene_rays(6, 4096, box=((-950.0, 30.0, -450.0), (950.0, 750.0, 450.0)))
         U = H.Unit("amd")
         f0, p0, pt0 = U.bvh_traverse(s, o, dd); f1, p1, pt1, _ = U.bvh_traverse_fast(s, o, dd)
         hit = f0 != 0
         assert np.array_equal(f0, f1) and np.array_equal(p0[hit], p1[hit]) and H.same_bits(pt0[hit], pt1[hit]) and hit.sum() > 1000, shrink
         L.scene_destroy(s)
+
+
+def test_out_of_range_lds_resident_scene_keeps_the_leaf_box_cull(H, L, orc_lib, devmath_mode):
+    """Coordinates beyond +-13 units, scene small enough to be staged in LDS (the Cornell box x 100): the reference tree is traversed decision by decision and
+    only the LEAF boxes -- which the reference never tests -- are rebuilt around their triangles at the scene's rounding bound, so the cull skips nothing that
+    could hit: equal to the replica and to the oracle bit for bit, with fewer triangle tests; also with the reference's inner boxes made to miss (test hook);
+    a camera beyond TerraAmdTraversalInfo::camera_limit sends that call down the replica traversal and last_call says so."""
+    import torch
+    from tools.scaled_hall import scaled
+
+    def render(mode, integ, shrink=None, cam_scale=1.0):
+        d = scaled(scenes.cornell_box(96, 64, 6, integrator=integ), 100.0)
+        d.camera_position = tuple(c * cam_scale for c in d.camera_position)
+        L.clear_error(); s = scenes.build_scene(L, d, tree_mode=mode, debug_shrink=shrink)
+        assert runtime.last_error() == "", runtime.last_error()
+        fb = runtime.DeviceFramebuffer(d.width, d.height)
+        rc = torch.zeros(d.width * d.height, dtype=torch.int32, device="cuda")
+        runtime.render_device(L, scenes.camera_of(d), s, fb, None, rc); torch.cuda.synchronize()
+        ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(s, C.byref(ti)))
+        st = runtime.Stats(); runtime.check(L.get_stats(s, C.byref(st)))
+        out = dict(pixels=fb.pixels_host().copy(), acc=fb.results_host()["acc"].copy(), calls=rc.cpu().numpy().copy(), ti=(ti.fast_tree, ti.leaf_cull, ti.last_call, ti.note.decode(), ti.camera_limit), stats=st.as_dict(), d=d)
+        L.scene_destroy(s)
+        return out
+
+    for integ in (0, 1, 2):
+        for shrink in (None, 20.0):
+            ref = render(0, integ, shrink); auto = render(2, integ, shrink)
+            assert auto["ti"][:3] == (0, 1, 2) and "leaf boxes rebuilt" in auto["ti"][3] and ref["ti"][2] == 1, auto["ti"]
+            assert same(H, ref["pixels"], auto["pixels"]) and same(H, ref["acc"], auto["acc"]) and np.array_equal(ref["calls"], auto["calls"]), (integ, shrink)
+            assert auto["stats"]["tri_tests"] < ref["stats"]["tri_tests"] and auto["stats"]["tri_tests"] + auto["stats"]["tri_culled"] == ref["stats"]["tri_tests"]
+            assert auto["stats"]["nodes"] == ref["stats"]["nodes"] and auto["stats"]["hits"] == ref["stats"]["hits"]
+        want = H.Unit("orc").render_pixels(ref["d"], threads=8)       # (unshrunk) the oracle's image of the scaled box
+        plain = render(2, integ)
+        assert same(H, plain["pixels"], want["pixels"]) and np.array_equal(plain["calls"].reshape(want["rand_calls"].shape).astype(np.uint64), want["rand_calls"].astype(np.uint64)), integ
+    far = render(2, 0, cam_scale=12.0)           # 12 x (0, 100, -340): beyond 8 x the largest coordinate (340)
+    assert far["ti"][1] == 1 and far["ti"][2] == 1 and abs(far["ti"][4] - 8 * 340.0) < 1.0
+    assert same(H, far["pixels"], render(0, 0, cam_scale=12.0)["pixels"]) and far["stats"]["tri_culled"] == 0
 
 
 def test_host_fast_tree_build_does_not_depend_on_its_threads(H, L, monkeypatch):

@@ -173,6 +173,9 @@ def import_dump(H, tmp_path, name, obj_text, mtl_text=None, extra=()):
         w = line.split()
         if w[0] == "object":
             objs.append(dict(attributes=int(w[5]), tris=[]))
+        elif w[0] == "m":      # m <preset> <attribute values, 3 per slot> e <emissive> ior <ior>
+            e = w.index("e")
+            objs[-1].update(preset=w[1], values=np.array(w[2:e], np.float32).reshape(-1, 3), emissive=np.array(w[e + 1:e + 4], np.float32), ior=np.float32(w[e + 5]))
         else:
             v = np.array(w[1:10] + w[11:20] + w[21:27], np.float32)
             objs[-1]["tris"].append(dict(p=v[0:9].reshape(3, 3), n=v[9:18].reshape(3, 3), uv=v[18:24].reshape(3, 2)))
@@ -243,8 +246,93 @@ def test_import_groups_and_materials(H, amd_lib, tmp_path):
            "g empty\n")                                                        # a group without faces makes no object
     o = import_dump(H, tmp_path, "groups", obj, mtl)
     assert [len(x["tris"]) for x in o] == [2, 1]
-    assert o[0]["attributes"] == 4 and o[1]["attributes"] == 4                  # shiny: Ks > 0 -> Phong (4 slots); lamp: `illum specular` -> Phong
+    # shiny has Ks > 0 but no Apollo `illum` word: its class stays invalid and Scene.cpp's switch falls through to diffuse; lamp: `illum specular` -> Phong
+    assert (o[0]["preset"], o[0]["attributes"]) == ("diffuse", 1) and (o[1]["preset"], o[1]["attributes"]) == ("phong", 4)
+    assert np.array_equal(o[0]["values"], [[0.5, 0.5, 0.5]]) and np.array_equal(o[1]["emissive"], [5, 5, 5])
     assert np.array_equal(o[1]["tris"][0]["uv"], [[0.25, 0.75]] * 3)
-    # this repo's other policy groups by material instead and keeps vn
+    # this repo's other policy groups by material instead, keeps vn and reads Ks > 0 as Phong
     o = import_dump(H, tmp_path, "groups_file", obj, mtl.replace("groups", "groups_file"), extra=["--normals", "file"])
     assert sorted(len(x["tris"]) for x in o) == [1, 1, 1]
+    assert sorted(x["preset"] for x in o) == ["diffuse", "phong", "phong"]
+
+
+MTL_CLASSES = """newmtl a_diffuse
+Kd 0.1 0.2 0.3
+illum diffuse
+newmtl b_specular
+Kd 0.4 0.5 0.6
+Ks 0.7 0.8 0.9
+Ns 32
+illum specular
+newmtl c_mirror
+Kd 0.11 0.12 0.13
+Ks 1 1 1
+illum mirror
+newmtl d_pbr
+Kd 0.21 0.22 0.23
+Pr 0.5
+Pm 1
+illum pbr
+newmtl e_disney
+Kd 0.31 0.32 0.33
+illum disney
+newmtl f_standard_mtl
+Kd 0.41 0.42 0.43
+Ks 0.5 0.5 0.5
+Ns 100
+illum 2
+newmtl g_lamp
+Kd 0 0 0
+Ke 7 8 9
+illum diffuse
+"""
+
+
+def test_import_material_class_table(H, amd_lib, tmp_path):
+    """one object per Apollo BSDF class (satellite/include/Apollo.h:80-87, set only by `illum <word>`, :877-897) through the reference client's
+    switch (satellite/src/Scene.cpp:193-230): specular -> Phong with (specular colour, albedo, exponent x3, pick 0) in TerraPresets.h's slot
+    order; diffuse, mirror, pbr, disney and the invalid class (standard MTL's `illum 2`) -> diffuse with Kd; Ke -> emissive; ior 1.5 always.
+    HAND-DERIVED from those lines (restated, not executed)."""
+    names = ["a_diffuse", "b_specular", "c_mirror", "d_pbr", "e_disney", "f_standard_mtl", "g_lamp"]
+    obj = "mtllib classes.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\n" + "".join(f"g {n}\nusemtl {n}\nf 1 2 3\n" for n in names)
+    from terra_amd import build
+    o = import_dump(H, tmp_path, "classes", obj, MTL_CLASSES)
+    assert len(o) == 7 and all(float(x["ior"]) == 1.5 for x in o)
+    f = np.float32
+    want = {0: [[0.1, 0.2, 0.3]], 2: [[0.11, 0.12, 0.13]], 3: [[0.21, 0.22, 0.23]], 4: [[0.31, 0.32, 0.33]], 5: [[0.41, 0.42, 0.43]], 6: [[0, 0, 0]]}
+    for k, kd in want.items():
+        assert o[k]["preset"] == "diffuse" and o[k]["attributes"] == 1 and np.array_equal(o[k]["values"], np.array(kd, f)), names[k]
+    # Phong slots (include/TerraPresets.h): 0 specular colour, 1 albedo, 2 exponent (to_constant(float) -> all three), 3 the sample-pick scratch = 0
+    assert o[1]["preset"] == "phong" and np.array_equal(o[1]["values"], np.array([[0.7, 0.8, 0.9], [0.4, 0.5, 0.6], [32, 32, 32], [0, 0, 0]], f))
+    assert np.array_equal(o[6]["emissive"], [7, 8, 9]) and all(not o[k]["emissive"].any() for k in range(6))
+    # the reference warns for the classes it cannot shade and goes on (Scene.cpp:215-220); so does the tool
+    exe = build_tool(H, tmp_path, "amd")
+    r = subprocess.run([str(exe), str(tmp_path / "classes.obj"), str(tmp_path / "unused.png"), "--no-render"], capture_output=True, text=True)
+    assert r.returncode == 0
+    for word, name in (("mirror", "c_mirror"), ("pbr", "d_pbr"), ("disney", "e_disney"), ("unclassified", "f_standard_mtl")):
+        assert any(word in ln and name in ln and "Defaulting to diffuse" in ln for ln in r.stderr.splitlines()), (word, r.stderr)
+    assert "a_diffuse" not in r.stderr and "b_specular" not in r.stderr
+    # this repo's own policy for standard MTL files reads Ks > 0 as Phong when there is no Apollo word
+    o2 = import_dump(H, tmp_path, "classes_file", obj.replace("classes.mtl", "classes_file.mtl"), MTL_CLASSES, extra=["--normals", "file"])
+    by_kd = {tuple(round(float(v), 2) for v in x["values"][1 if x["preset"] == "phong" else 0]): x["preset"] for x in o2}
+    assert by_kd[(0.41, 0.42, 0.43)] == "phong" and by_kd[(0.11, 0.12, 0.13)] == "diffuse" and by_kd[(0.4, 0.5, 0.6)] == "phong"
+
+
+def test_import_negative_indices_and_multiple_usemtl(H, amd_lib, tmp_path):
+    """relative (negative) indices count back from the elements read so far (the OBJ rule; -1 = the last `v` / `vt` before the face);
+    several `usemtl` inside one group leave ONE object whose material is the last of them (Apollo.h:1101-1130)"""
+    mtl = "newmtl one\nKd 1 0 0\nillum diffuse\nnewmtl two\nKd 0 1 0\nillum diffuse\nnewmtl three\nKd 0 0 1\nillum specular\n"
+    obj = ("mtllib neg.mtl\ng all\nusemtl one\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0.5 0.25\nf -3/-1 -2/-1 -1/-1\n"
+           "usemtl two\nv 0 0 2\nf -4 -3 -1\nusemtl three\nf 1 2 -1\n")
+    o = import_dump(H, tmp_path, "neg", obj, mtl)
+    assert len(o) == 1 and len(o[0]["tris"]) == 3 and o[0]["preset"] == "phong" and np.array_equal(o[0]["values"][1], [0, 0, 1])
+    t0, t1, t2 = o[0]["tris"]
+    assert np.array_equal(t0["p"], [[0, 1, 0], [1, 0, 0], [0, 0, 0]]) and np.array_equal(t0["uv"], [[0.5, 0.25]] * 3)      # (c, b, a), z negated
+    assert np.array_equal(t1["p"], [[0, 0, -2], [1, 0, 0], [0, 0, 0]])                                                      # -4 -3 -1 = v1 v2 v4
+    assert np.array_equal(t2["p"], [[0, 0, -2], [1, 0, 0], [0, 0, 0]]) and not t1["uv"].any()                               # 1 2 -1  = v1 v2 v4
+
+
+def test_help_states_that_the_importer_is_restated(H, amd_lib, tmp_path):
+    exe = build_tool(H, tmp_path, "amd")
+    r = subprocess.run([str(exe), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "restated, not executed" in r.stdout and "Apollo.h" in r.stdout

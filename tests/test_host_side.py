@@ -177,8 +177,9 @@ def test_automatic_traversal_decision(H, L):
     # explicit modes are obeyed without a check
     assert _decision(L, scenes.cornell_box(32, 32, 1), 0)[:3] == (0, 0, 0)
     assert _decision(L, scenes.cornell_box(32, 32, 1), 1)[:3] == (1, 1, 0)
-    # coordinates beyond the range in which the 1e-4 box margin provably exceeds rounding error: never the cull; a scene that is not LDS-resident keeps the
-    # fast tree with the reference's reachability replayed per accepted hit, a resident one runs the replica -- with the reason either way
+    # coordinates beyond the range in which the 1e-4 box margin provably exceeds rounding error: a scene that is not LDS-resident keeps the fast tree with the
+    # reference's reachability replayed per accepted hit; a resident one keeps the reference tree and culls with LEAF boxes rebuilt at the scene's rounding bound --
+    # with the reason either way
     d = soup_scene(H, 300, 9)
     for o in d.objects:
         o.triangles = (o.triangles * np.float32(40.0)).astype(np.float32)
@@ -188,7 +189,12 @@ def test_automatic_traversal_decision(H, L):
     for o in d.objects:
         o.triangles = (np.asarray(o.triangles, np.float32) * np.float32(40.0)).astype(np.float32)
     mode, fast, cull, cmax, note = _decision(L, d)
-    assert (fast, cull) == (0, 0) and cmax > 13.0 and "exceeds" in note and "replica" in note
+    assert (fast, cull) == (0, 1) and cmax > 13.0 and "exceeds" in note and "leaf boxes rebuilt" in note
+    # the test hook that shrinks the device's copy of the reference boxes voids the in-range containment proof: no shortcut that rests on it
+    sc = scenes.build_scene(L, scenes.cornell_box(32, 32, 1), debug_shrink=0.01)
+    ti = runtime.TraversalInfo(); assert L.traversal_info(sc, C.byref(ti)) == 0
+    assert (ti.fast_tree, ti.leaf_cull) == (0, 0) and "TEST HOOK" in ti.note.decode()
+    L.scene_destroy(sc)
     # non-finite coordinates never pass
     d = soup_scene(H, 50, 10); d.objects[0].triangles[0, 0, 0] = np.float32("nan")
     assert _decision(L, d)[1:3] == (0, 0)
