@@ -24,7 +24,7 @@ depend on N and a 1/8 share of the frame still fills a GPU.
 Also on the JSON line (rank 0):
   roofline     -- against the resource that binds the render kernel (DESIGN.md "Roofline"):
                   bound "valu" for scenes staged in LDS: achieved = VALU wave-instructions per second (SQ_INSTS_VALU of the
-                  committed PMC summary profiles/r02_pmc.json / the kernel time measured live with HIP events), peak = 1024
+                  committed PMC summary profiles/rNN_pmc.json / the kernel time measured live with HIP events), peak = 1024
                   SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; lane_util and the LDS bank-conflict share beside it;
                   bound "l2_fabric" for scenes read from global memory: achieved = bytes the L2 moved on its fabric side
                   (FETCH_SIZE/WRITE_SIZE PMC passes, Infinity Cache hits included) per second, peak = the 8 TB/s HBM figure.
@@ -271,16 +271,23 @@ def pmc_key(workload_name, tree, integrator, split, spp_override):
     return f"{workload_name}|tree={tree}|integrator={integrator}|split={split}" + (f"|spp={spp_override}" if spp_override else "")
 
 
-def roofline(key, st, kernel_ms, lds_resident, world):
-    """st: device work counters per launch; the PMC record (per launch of the render kernel) comes from profiles/r02_pmc.json"""
+def pmc_file():
+    """the newest committed PMC summary (profiles/rNN_pmc.json, written by tools/profile_round.py)"""
+    fs = sorted((ROOT / "profiles").glob("r[0-9][0-9]_pmc.json"))
+    return fs[-1] if fs else None
+
+
+def roofline(key, st, kernel_ms, lds_resident, world, pmc=None):
+    """st: device work counters per launch; the PMC record (per launch of the render kernel) comes from the newest profiles/rNN_pmc.json"""
     alg = algorithmic_bytes(st)
     rec = {}
-    f = ROOT / "profiles" / "r02_pmc.json"
-    if f.exists():
+    f = Path(pmc) if pmc else pmc_file()
+    if f is not None and f.exists():
         rec = json.loads(f.read_text()).get(key, {})
     t = kernel_ms * 1e-3
     out = {"kernel": "terra_render_kernel", "kernel_ms": round(kernel_ms, 3), "rank0_only": world > 1,
-           "algorithmic_bytes_per_launch": int(alg), "algorithmic_gbs": round(alg / t / 1e9, 1), "pmc_record": key if rec else None}
+           "algorithmic_bytes_per_launch": int(alg), "algorithmic_gbs": round(alg / t / 1e9, 1), "pmc_record": key if rec else None,
+           "pmc_file": ("profiles/" + f.name) if (rec and f is not None) else None}
     if rec:
         out["pmc_stale"] = rec.get("source_digest") != source_digest()
         out["pmc_kernel_ms"] = rec.get("kernel_ms")
@@ -301,7 +308,7 @@ def roofline(key, st, kernel_ms, lds_resident, world):
         out.update({"bound": "valu" if lds_resident else "l2_fabric", "achieved": None, "peak": VALU_PEAK_GINST if lds_resident else HBM_PEAK_GBS,
                     "unit": "G wave-instr/s" if lds_resident else "GB/s", "frac": None})
     if lds_resident:
-        out["note"] = ("scene staged in LDS: the kernel is bound by VALU issue. achieved = SQ_INSTS_VALU (profiles/r02_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
+        out["note"] = ("scene staged in LDS: the kernel is bound by VALU issue. achieved = SQ_INSTS_VALU (profiles/rNN_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
                        "A stream of nothing but v_add_f32 sustains 0.96 G/s per SIMD on this part and min/max/cmp/cndmask/f64/integer-multiply streams 0.57 (profiles/r02_measurements/valu_rates.log), so frac ~0.7 is "
                        "saturation for this instruction mix; lane_util says how many of the issued lanes did work; `traffic` is what HBM moved (framebuffer only)")
     else:

@@ -123,6 +123,9 @@ struct DevScene {
     // level. Bit 31 stands for every level from 31 up.
     const uint32_t*    fast_leaf_mask;
     uint32_t           reach;
+    // (cos, sin) of 2 * terra_PI * (k * 2^-24) for k = 0 .. 2^24 - 1: the azimuth the BSDF samplers make of a stream-B variate, tabulated once per device
+    // (128 MB of HBM; trace_device.h azimuth_fetch). nullptr = compute.
+    const float2*      sincos24;
     // environment lighting (terra_amd_set_environment_lighting; off = the reference's behaviour):
     // 0 off, 1 constant env_color, 2 lat-long lookup of textures[env_tex] by ray direction
     int32_t  env_mode;

@@ -295,11 +295,16 @@ TD void deposit ( float* acc_lds, V3 Lo ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_
 // (paths have random lengths: with 64-sample chunks 13 % of the lane time of the Cornell frame was spent in that ramp-down,
 // profiles/r02_measurements/phase_cornell.log) and that the launch has no tail of half-empty rounds.
 // Exit: the queue only grows; a lane that finds the pool empty and the queue beyond the job space leaves the loop for good.
+// What it buys depends on the loop. The decoupled loops (scenes traversed from global memory), whose traversal hands finished lanes back early, gain 9 % (hall,
+// sphere scene). The coupled loops (LDS-resident scenes) gain 1.5 % (Simple) to 3.5 % (Direct) -- far less than the 13 % of lane time that the ramp-down of a plain
+// launch leaves idle, because a wave's cost is the sum over its iterations of the LONGEST lane's node and leaf loops, and a wave that ramps down with few live lanes
+// runs short loops: with the queue the lanes of the Cornell frame are 97.5 % alive instead of 87 %, yet the frame needs as many node-loop iterations (4.5e8),
+// leaf-loop iterations and shading executions as before (profiles/r03_measurements/phase_cornell_queue.log, ab_job_queue.log).
 struct Jobs { uint32_t px, py, s; bool exhausted; };
 
 #ifndef TERRA_JOB_FETCH_MIN      // (coupled loop) lanes at a job boundary switch jobs together once this many wait there -- or no lane of the wave is tracing:
-#define TERRA_JOB_FETCH_MIN 4    // the switch (pixel decode, stream keys: ~250 instructions) then runs for several lanes at once
-#endif
+#define TERRA_JOB_FETCH_MIN 1    // the switch (pixel decode, stream keys: ~250 instructions) then runs for several lanes at once. 1 measured best (Cornell: 1 -> 71.5 ms,
+#endif                           // 2 -> 72.8, 4 -> 73.6, 8 -> 75.9 at 4 blocks per CU; 65.8 / 66.2 / 66.7 at 5; profiles/r03_measurements/ab_job_queue.log)
 #define TERRA_JOB_BATCH 64u
 #define TERRA_JOB_NONE 0xffffffffu
 
@@ -355,8 +360,9 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
     uint32_t job = next + ahead;
     bool got = ahead < take;
     next += take;
-    if ( take < n && next < total ) {                            // the pool ran dry: the next batch of the queue (one atomic by the first lane here), for the lanes still without a job
-                                                                 // (next == total: an earlier batch already came back beyond the job space -- nothing is left, no need to ask again)
+    if ( take < n && next < total && p.job_queue ) {             // the pool ran dry: the next batch of the queue (one atomic by the first lane here), for the lanes still without a job
+                                                                 // (next == total: an earlier batch already came back beyond the job space -- nothing is left, no need to ask again;
+                                                                 //  no queue: a plain launch, every lane has the one job of its own index)
         uint32_t base = 0;
         if ( ahead == 0 ) base = atomicAdd ( p.job_queue, TERRA_JOB_BATCH );
         base = gridDim.x * 256u + ( uint32_t ) __builtin_amdgcn_readfirstlane ( ( int ) base );
@@ -434,7 +440,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Ray ray_a;
                         pend = mis_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
                         b_o = point + sf.normal * 0.0001f;        // surface_ray ( sf, point, bsdf_dir, 1.f ) without the divisions
-                        cont = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
+                        cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
                         cont_o = point + sf.normal * 0.0001f;     // (the divisions of surface_ray are redone when the ray starts)
                         ro = ray_a.o; rd = ray_a.d; job = 1; start = true;
                     } else {
@@ -485,7 +491,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         V3 wo = neg ( ray.d );
                         Ray shadow_ray;
                         pend = direct_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
-                        cont = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
+                        cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
                         cont_o = point + sf.normal * 0.0001f;     // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are taken when the ray starts
                         ro = shadow_ray.o; rd = shadow_ray.d; shadow = true; start = true;
                     } else {
@@ -520,10 +526,11 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 if ( have_ray ) {
                     if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
+                        const PathDraws pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );       // (these integrators draw nothing themselves: the variates, and the table load, come first)
                         V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
                         V3 wo = neg ( ray.d ), wi;
                         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, point, wo, throughput, bounce, rs.b, c );
-                        next = path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
+                        next = path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                         if ( next ) { ro = point + sf.normal * 0.0001f; rd = wi; }       // surface_ray ( sf, point, wi, 1.f ); its reciprocals are taken below
                     } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {
                         throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
@@ -565,13 +572,16 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
             ray = make_ray ( ro, rd );
             Surface sf;
             PS_WAVE ( c, kPsRayIter ); PS_LANE ( c, kPsRayLanes );
-            RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
+            constexpr bool pre_draw = !TERRA_IS_LIGHT ( INTEGRATOR );      // integrators that draw nothing themselves: the continuation variates come before the surface set-up
+            PathDraws pd;
+            RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c, pre_draw ? &pd : nullptr, pre_draw ? &rs.b : nullptr );
             bool end = !h.hit;
             if ( h.hit ) {
                 PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
                 V3 wo = neg ( ray.d ), wi;
                 Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
-                end = !path_continue<COUNT, KINDS> ( sf, wo, throughput, bounce, p.bounces, rs.b, c, wi );
+                if ( !pre_draw ) pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );
+                end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                 if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }      // surface_ray ( sf, h.point, wi, 1.f ): its make_ray is the one at the top of this block
             } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
                 throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
@@ -634,8 +644,8 @@ void terra_plan_fast_tree ( DevRenderParams& p ) {
 #ifndef TERRA_LEAF_CAP_MIN       // smallest leaf list worth an extra resident block (with the decoupled loop, hall: 5 blocks x 6 entries
 #define TERRA_LEAF_CAP_MIN 6     // 391 ms vs 4 blocks x 14 entries 400 ms, Direct 473 vs 487 ms; profiles/r01_measurements/ab_lc*.log)
 #endif
-#ifndef TERRA_LDS_BUDGET
-#define TERRA_LDS_BUDGET ( 32 * 1024 )
+#ifndef TERRA_LDS_BUDGET          // per block, so that FIVE blocks stay resident per CU: a CU does not hand out all of its 160 KB -- 5 x 31,632 B fit, 5 x 32,656 B
+#define TERRA_LDS_BUDGET ( TERRA_LDS_CU_KB * 1024 / 5 )      // do not (measured: 4.57 -> 3.67 waves per SIMD and 65.6 -> 74.4 ms on the Cornell frame, profiles/r03_measurements/lds_cliff.log)
 #endif
 #ifndef TERRA_LEAF_CAP_RESIDENT_MIN
 #define TERRA_LEAF_CAP_RESIDENT_MIN 8
@@ -677,14 +687,11 @@ static uint32_t resident_blocks ( const void* fn, size_t lds ) {
     Key& k = cache[used < 8 ? used++ : 7]; k.fn = fn; k.lds = lds; k.dev = dev; k.blocks = blocks;
     return blocks;
 }
-#ifndef TERRA_PERSISTENT      // 0: one block per virtual block, as a plain launch (A/B of the job queue)
-#define TERRA_PERSISTENT 1
-#endif
 template <int I, int COUNT, int MODE, int KINDS>
 static hipError_t launch_instance ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
     auto fn = terra_render_kernel<I, COUNT, MODE, KINDS>;
     uint32_t grid = p.job_blocks;
-    if ( TERRA_PERSISTENT ) { const uint32_t cap = resident_blocks ( reinterpret_cast<const void*> ( fn ), lds ); if ( grid > cap ) grid = cap; }
+    if ( p.job_queue ) { const uint32_t cap = resident_blocks ( reinterpret_cast<const void*> ( fn ), lds ); if ( grid > cap ) grid = cap; }
     hipLaunchKernelGGL ( fn, dim3 ( grid ), dim3 ( 256 ), lds, stream, p );
     return hipGetLastError();
 }
@@ -710,10 +717,17 @@ static hipError_t launch_one ( const DevRenderParams& p, size_t lds, hipStream_t
     return launch_mode<I, 0> ( p, lds, stream );
 }
 
-// p.job_blocks, p.job_queue (zeroed on `stream` by the caller), p.partials must be set (scene_host.cpp launch_render)
+// p.job_blocks and p.partials must be set (scene_host.cpp launch_render); p.job_queue (a zeroed word) = persistent grid fed by the queue, nullptr = plain launch
+bool terra_render_wants_queue ( const DevRenderParams& p ) {
+#ifdef TERRA_QUEUE_NEVER         // A/B builds: every loop launched plainly
+    ( void ) p; return false;
+#else
+    ( void ) p; return true;
+#endif
+}
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) {
     if ( p.job_blocks == 0 ) return hipSuccess;
-    if ( !p.job_queue || !p.partials ) return hipErrorInvalidValue;
+    if ( !p.partials ) return hipErrorInvalidValue;
     size_t lds = terra_lds_bytes ( p );
     switch ( p.integrator ) {
         case 0: return launch_one<0> ( p, lds, stream );

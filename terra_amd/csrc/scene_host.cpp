@@ -527,6 +527,21 @@ static void build_reach_tables ( const std::vector<DevNode>& nodes, const std::v
     }
 }
 
+// DevScene::sincos24, one table per device for the life of the process (128 MB of its 288 GB; filled by tdm_sincosf_pair itself, ~1 ms). nullptr when it cannot
+// be had (or TERRA_AMD_NO_SINCOS_TABLE is set: A/B runs) -- the kernels then compute.
+static const float2* sincos_table_of ( int device ) {
+    static std::mutex lock; static const float2* tables[64]; static bool tried[64];
+    if ( device < 0 || device >= 64 || getenv ( "TERRA_AMD_NO_SINCOS_TABLE" ) ) return nullptr;
+    std::lock_guard<std::mutex> g ( lock );
+    if ( tried[device] ) return tables[device];
+    tried[device] = true;
+    float2* t = nullptr;
+    if ( hipMalloc ( ( void** ) &t, sizeof ( float2 ) << 24 ) != hipSuccess ) { ( void ) hipGetLastError(); return nullptr; }
+    if ( terra_fill_sincos24 ( t, nullptr ) != hipSuccess || hipDeviceSynchronize() != hipSuccess ) { ( void ) hipGetLastError(); ( void ) hipFree ( t ); return nullptr; }
+    tables[device] = t;
+    return t;
+}
+
 // validates that every material can run on the device and uploads the flattened scene
 static int upload_scene ( Scene* s ) {
     const size_t nobj = s->objects_pop;
@@ -868,6 +883,7 @@ static int upload_scene ( Scene* s ) {
     s->dev.reach = ( s->reach && have_fast && !reach_tabs.leaf_parent.empty() ) ? 1u : 0u;
     s->dev.ref_replay = s->dev.reach ? ( const DevReplay* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
+    s->dev.sincos24 = sincos_table_of ( s->device );
     s->device_ok = true;
     return 0;
 }
@@ -1017,6 +1033,9 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
         if ( s->fast_on_device ) p.lds_nodes = 0;      // the device-built tree is not numbered top-levels-first: nothing worth staging
     }
     p.leaf_cull = ( s->cull_ok && cam_ok && p.lds_mode != 2 ) ? 1u : 0u;
+    // the azimuth table pays where VALU issue binds (LDS-resident scenes: Cornell Simple 65.8 -> 64.2 ms, Direct 145.2 -> 142.5); the kernels that wait on memory anyway
+    // lose by one more dependent load per shaded hit (sphere scene 395 -> 419 ms, hall 282 -> 284; profiles/r03_measurements/ab_sincos_table.log)
+    if ( p.lds_mode != 1 ) p.scene.sincos24 = nullptr;
     // what this call runs (TerraAmdTraversalInfo::last_call): the commit-time decision can be overridden per call by the camera position
     s->last_call.store ( p.lds_mode == 2 ? ( s->dev.reach ? kTerraAmdCallFastTreeReach : kTerraAmdCallFastTree ) : ( p.leaf_cull ? kTerraAmdCallLeafCull : kTerraAmdCallReplica ), std::memory_order_relaxed );
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
@@ -1068,7 +1087,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
     hipError_t e = hipMemsetAsync ( scratch, 0, header, stream );
     p.split = split; p.split_log2 = 0; while ( ( 1u << p.split_log2 ) < split ) ++p.split_log2;
     p.chunk_spp = p.spp / split; p.partials = ( float4* ) ( ( char* ) scratch + header );
-    p.job_blocks = blocks * split; p.job_queue = ( uint32_t* ) scratch;
+    p.job_blocks = blocks * split; p.job_queue = terra_render_wants_queue ( p ) ? ( uint32_t* ) scratch : nullptr;
     {   // the job decode divides block numbers by launch constants: as multiplications by ceil(2^32 / d), exact while (largest dividend) * divisor < 2^32
         const uint64_t bpt = p.tile_size / 16, bpt2 = bpt * bpt, tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size, tiles_y = ( p.h + p.tile_size - 1 ) / p.tile_size;
         auto magic = [] ( uint64_t d ) { return d <= 1 ? 0u : ( uint32_t ) ( ( ( 1ull << 32 ) + d - 1 ) / d ); };

@@ -726,8 +726,14 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
 
 struct RaycastResult { bool hit; uint32_t object, tri_in_object, tri; V3 point; };
 
+struct Azimuth { float sn, cs; bool have; };
+struct PathDraws { float e0, e1, e2, e3; Azimuth az; };
+template <int COUNT> TD PathDraws path_draw ( const float2* sincos24, Pcg32& rb, Counters& c );
+
+// pre / rb (optional): a hit draws the path's four continuation variates (path_draw) BEFORE the surface is set up, so that the azimuth table load they issue
+// is in flight during terra_surface_init's arithmetic -- only for integrators that draw nothing of their own between the hit and the BSDF sample
 template <int COUNT, int MODE, int KINDS>
-TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Counters& c ) {
+TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Counters& c, PathDraws* pre = nullptr, Pcg32* rb = nullptr ) {
     Ray r = in;
     r.o = r.o + r.d * 0.001f;
     RayState st = ray_state_init ( r );
@@ -739,6 +745,7 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
     res.point = res.hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
     if ( res.hit ) {
         uint32_t nattr;
+        if ( pre ) *pre = path_draw<COUNT> ( T.sc.sincos24, *rb, c );
         surface_init<MODE, KINDS> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
         if ( MODE == 2 ) res.tri = T.sc.mats[res.object].first_tri + res.tri_in_object;      // back to the soup index (lights, areas)
         if ( COUNT ) ++c.hits;
@@ -756,11 +763,30 @@ TD Ray surface_ray ( const Surface& sf, V3 p, V3 d, float sign ) {
 // BSDF presets
 // -----------------------------------------------------------------------------
 
-TD V3 diffuse_sample ( const Surface& sf, float e1, float e2 ) {
+// sin / cos of the azimuth 2 * terra_PI * e that the samplers make of one variate (src/TerraPresets.c:39-40). A stream-B variate is u24 * 2^-24
+// (rng.h), so over the render path this is a pure function of 24 bits: DevScene::sincos24 tabulates it -- every entry computed by tdm_sincosf_pair itself, at
+// library start-up (unit_kernels.hip terra_fill_sincos24) -- and one 8-byte load replaces ~100 double-precision instructions (the glibc algorithm restated in
+// dev_math.h). Any other argument (unit-level calls with arbitrary variates, a sampler-driven first bounce) takes the computation.
+TD Azimuth azimuth_none() { Azimuth a; a.sn = 0.f; a.cs = 1.f; a.have = false; return a; }
+// the table entry of variate e, if e is one of the 2^24 stream-B values (the load is issued here; the caller uses it as late as it can)
+TD Azimuth azimuth_fetch ( const float2* tab, float e ) {
+    Azimuth a = azimuth_none();
+    const float x = e * 16777216.f;
+    if ( tab && e >= 0.f && x < 16777216.f ) {
+        const uint32_t k = ( uint32_t ) x;
+        if ( ( float ) k == x ) { const float2 v = tab[k]; a.cs = v.x; a.sn = v.y; a.have = true; }
+    }
+    return a;
+}
+TD void azimuth_sincos ( const Azimuth& az, float e, float& sn, float& cs ) {
+    if ( az.have ) { sn = az.sn; cs = az.cs; }
+    else tdm_sincosf_pair ( 2 * TERRA_PI_F * e, sn, cs );
+}
+
+TD V3 diffuse_sample ( const Surface& sf, float e1, float e2, const Azimuth& az ) {
     float r = sqrtf ( e1 );
-    float theta = 2 * TERRA_PI_F * e2;
     float sn, cs;
-    tdm_sincosf_pair ( theta, sn, cs );
+    azimuth_sincos ( az, e2, sn, cs );
     float x = r * cs;
     float z = r * sn;
     V3 wi = v3 ( x, sqrtf ( sel_max ( 0.f, 1 - e1 ) ), z );
@@ -778,9 +804,9 @@ TD void phong_kd_ks ( const Surface& sf, float& kd, float& ks ) {
 }
 TD V3 phong_reflect ( const Surface& sf, V3 wo ) { return sf.normal * ( 2.f * dot ( wo, sf.normal ) ) - wo; }
 
-TD V3 phong_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
+TD V3 phong_sample ( Surface& sf, float e1, float e2, float e3, V3 wo, const Azimuth& az ) {
     float kd, ks; phong_kd_ks ( sf, kd, ks );
-    if ( e3 < kd ) { sf.attr[3].x = 1.f; return diffuse_sample ( sf, e1, e2 ); }
+    if ( e3 < kd ) { sf.attr[3].x = 1.f; return diffuse_sample ( sf, e1, e2, az ); }
     sf.attr[3].x = -1.f;
     V3 wr = phong_reflect ( sf, wo );
     Basis b = make_basis ( wr );
@@ -823,14 +849,13 @@ TD float ggx_G1 ( V3 v, V3 n, V3 h, float alpha2 ) {
     float tan2 = ( 1.f - VoN2 ) / VoN2;        // Smith G1 w.r.t. the normal (Walter 2007 eq. 34), see oracle note
     return 2.f / ( sqrtf ( 1 + alpha2 * tan2 ) + 1 );
 }
-TD V3 ggx_sample ( const Surface& sf, float e1, float e2, V3 wo ) {
+TD V3 ggx_sample ( const Surface& sf, float e1, float e2, V3 wo, const Azimuth& az ) {
     float alpha = sf.attr[1].x;
     float t2 = alpha * alpha * e1 / ( 1.f - e1 );
     float cos_t = 1.f / sqrtf ( 1.f + t2 );
     float sin_t = sqrtf ( sel_max ( 0.f, 1.f - cos_t * cos_t ) );
-    float phi = 2 * TERRA_PI_F * e2;
     float sn, cs;
-    tdm_sincosf_pair ( phi, sn, cs );
+    azimuth_sincos ( az, e2, sn, cs );
     V3 h = v3 ( sin_t * cs, cos_t, sin_t * sn );
     h = normalize ( basis_apply ( make_basis ( sf.normal ), h ) );
     float HoV = sel_max ( 0.f, dot ( h, wo ) );
@@ -894,12 +919,13 @@ TD V3 glass_eval ( const Surface& sf, V3 wi ) {
 // (bit k = DevBsdfKind k): a diffuse-only scene compiles to straight-line diffuse code, which is
 // what keeps the Simple kernel inside 96 VGPRs (5 waves/SIMD) without scratch.
 #define TERRA_KINDS_ALL 63
+// az: the azimuth of the SECOND variate (e2), if its table entry was fetched (azimuth_fetch) -- what the diffuse and GGX samplers and Phong's diffuse branch use
 template <int KINDS>
-TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo ) {
-    if ( ( KINDS & 2 ) && ( KINDS == 2 || sf.bsdf == kDevBsdfPhong ) ) return phong_sample ( sf, e1, e2, e3, wo );
-    if ( ( KINDS & 4 ) && ( KINDS == 4 || sf.bsdf == kDevBsdfGGX ) ) return ggx_sample ( sf, e1, e2, wo );
+TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo, const Azimuth& az ) {
+    if ( ( KINDS & 2 ) && ( KINDS == 2 || sf.bsdf == kDevBsdfPhong ) ) return phong_sample ( sf, e1, e2, e3, wo, az );
+    if ( ( KINDS & 4 ) && ( KINDS == 4 || sf.bsdf == kDevBsdfGGX ) ) return ggx_sample ( sf, e1, e2, wo, az );
     if ( ( KINDS & 8 ) && ( KINDS == 8 || sf.bsdf == kDevBsdfGlass ) ) return glass_sample ( sf, e3, wo );
-    return diffuse_sample ( sf, e1, e2 );
+    return diffuse_sample ( sf, e1, e2, az );
 }
 template <int KINDS>
 TD float bsdf_pdf ( const Surface& sf, V3 wi, V3 wo ) {
@@ -928,8 +954,9 @@ TD float triangle_area ( V3 a, V3 b, V3 cc ) { return length ( cross ( b - a, cc
 
 struct LightSample { uint32_t light_object; uint32_t tri_in_object; uint32_t tri; float pick_pdf; V3 pos, norm; };
 
-template <int COUNT>
-TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c ) {
+// (MODE 1: the light's triangle and vertex normals come from the block's LDS copy of the scene)
+template <int COUNT, int MODE = 0>
+TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c, const Tracer* T = nullptr ) {
     LightSample ls;
     float e = ( float ) ( ( double ) randf ( rb, c, COUNT ) - 1e-4 );
     double xl = ( double ) e * ( double ) sc.n_lights;
@@ -941,8 +968,8 @@ TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c ) 
     if ( k >= l.tri_count ) k = l.tri_count - 1;
     ls.light_object = l.object; ls.tri_in_object = k; ls.tri = l.first_tri + k;
     float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
-    const float4* tris = reinterpret_cast<const float4*> ( sc.tris );
-    const float4* props = reinterpret_cast<const float4*> ( sc.props );
+    const float4* tris = ( MODE == 1 && T ) ? reinterpret_cast<const float4*> ( T->l_tris ) : reinterpret_cast<const float4*> ( sc.tris );
+    const float4* props = ( MODE == 1 && T ) ? T->l_props : reinterpret_cast<const float4*> ( sc.props );
     float4 t0 = tris[3 * ls.tri + 0], t1 = tris[3 * ls.tri + 1], t2 = tris[3 * ls.tri + 2];
     float4 p0 = props[4 * ls.tri + 0], p1 = props[4 * ls.tri + 1], p2 = props[4 * ls.tri + 2];
     float s = sqrtf ( e1 );
@@ -958,7 +985,7 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
     const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
     if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
-    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    LightSample ls = draw_light_sample<COUNT, MODE> ( sc, rb, c, &T );
     V3 p_to_light = ls.pos - p;
     V3 wi = normalize ( p_to_light );
     Surface lsf;
@@ -1016,7 +1043,7 @@ TD MisPending mis_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throug
     V3 Lo = v3 ( 0, 0, 0 );
     if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
     float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT ), e3 = randf ( rb, c, COUNT );
-    V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo );
+    V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo, azimuth_fetch ( sc.sincos24, e2 ) );
     LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
     MisPending m;
     m.a_hid = Lo; m.a_vis = Lo; m.expected = ls.tri; m.p = p; m.light_object = ls.light_object; m.t_before = throughput;
@@ -1073,8 +1100,8 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
     if ( DEBUG_WEIGHTS ) { if ( bounce != 0 ) return Lo; }
     else if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
     float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT ), e3 = randf ( rb, c, COUNT );
-    V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo );
-    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo, azimuth_fetch ( sc.sincos24, e2 ) );
+    LightSample ls = draw_light_sample<COUNT, MODE> ( sc, rb, c, &T );
     {
         V3 p_to_light = ls.pos - p;
         V3 wi = normalize ( p_to_light );
@@ -1174,20 +1201,34 @@ TD V3 integrate ( const Tracer& T, const Ray& ray, Surface& sf, V3 p, V3 wo, V3 
 // The tail of one terra_trace iteration after the integrator's term (reference src/Terra.c:1066-1094): sample the BSDF, weight the
 // throughput, play Russian roulette. Returns true when the path goes on (then `bounce` was advanced and wi is the next direction; the
 // caller forms the next ray from the hit point). Same operations, draws and order in all four loops of the kernel.
-template <int COUNT, int KINDS>
-TD bool path_continue ( Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, uint32_t max_bounces, Pcg32& rb, Counters& c, V3& wi ) {
-    float e0 = randf ( rb, c, COUNT ), e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
-    wi = bsdf_sample<KINDS> ( sf, e0, e1, e2, wo );
+// The four variates are consecutive draws of stream B whatever the surface is, so they can be drawn -- and the azimuth table entry requested -- BEFORE the
+// surface is set up (path_draw), which hides the load behind terra_surface_init's work; integrators that draw from the stream themselves (Direct, MIS) call
+// path_draw after their own draws, as the reference's order demands.
+template <int COUNT>
+TD PathDraws path_draw ( const float2* sincos24, Pcg32& rb, Counters& c ) {
+    PathDraws d;
+    d.e0 = randf ( rb, c, COUNT ); d.e1 = randf ( rb, c, COUNT ); d.e2 = randf ( rb, c, COUNT );
+    d.az = azimuth_fetch ( sincos24, d.e1 );
+    d.e3 = randf ( rb, c, COUNT );
+    return d;
+}
+template <int KINDS>
+TD bool path_continue ( Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, uint32_t max_bounces, const PathDraws& d, V3& wi ) {
+    wi = bsdf_sample<KINDS> ( sf, d.e0, d.e1, d.e2, wo, d.az );
     float pdf = sel_max ( bsdf_pdf<KINDS> ( sf, wi, wo ), ( float ) 1e-4 );
     V3 f = bsdf_eval<KINDS> ( sf, wi, wo ) * ( 1.f / pdf );
     throughput = had ( throughput, f );
     throughput = throughput * dot ( sf.normal, wi );
     float pr = sel_max ( throughput.x, sel_max ( throughput.y, throughput.z ) );
-    float e3 = randf ( rb, c, COUNT );
-    if ( e3 > pr ) return false;
+    if ( d.e3 > pr ) return false;
     throughput = throughput * ( float ) ( 1.0 / ( ( double ) pr + 1e-4 ) );
     ++bounce;
     return bounce <= max_bounces;
+}
+template <int COUNT, int KINDS>
+TD bool path_continue ( const DevScene& sc, Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, uint32_t max_bounces, Pcg32& rb, Counters& c, V3& wi ) {
+    const PathDraws d = path_draw<COUNT> ( sc.sincos24, rb, c );
+    return path_continue<KINDS> ( sf, wo, throughput, bounce, max_bounces, d, wi );
 }
 
 // -----------------------------------------------------------------------------
@@ -1208,7 +1249,7 @@ TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counte
         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rb, c );
         V3 wi;
         uint32_t next_bounce = bounce;
-        if ( !path_continue<COUNT, KINDS> ( sf, wo, throughput, next_bounce, bounces, rb, c, wi ) ) break;
+        if ( !path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, next_bounce, bounces, rb, c, wi ) ) break;
         ray = surface_ray ( sf, h.point, wi, 1.f );
     }
     return Lo;

@@ -192,7 +192,7 @@ __global__ void k_bsdf ( int kind, int n, float* surfaces47, const float* e3, co
     for ( int a = 0; a < 4; ++a ) sf.attr[a] = v3p ( q + 23 + 3 * a );
     sf.bsdf = kind; sf.ior = q[22];
     V3 wo = v3p ( wo3 + 3 * i );
-    V3 wi = bsdf_sample<TERRA_KINDS_ALL> ( sf, e3[3 * i], e3[3 * i + 1], e3[3 * i + 2], wo );
+    V3 wi = bsdf_sample<TERRA_KINDS_ALL> ( sf, e3[3 * i], e3[3 * i + 1], e3[3 * i + 2], wo, azimuth_none() );
     float p = bsdf_pdf<TERRA_KINDS_ALL> ( sf, wi, wo );
     V3 f = bsdf_eval<TERRA_KINDS_ALL> ( sf, wi, wo );
     wi3[3 * i] = wi.x; wi3[3 * i + 1] = wi.y; wi3[3 * i + 2] = wi.z;
@@ -307,5 +307,17 @@ hipError_t terra_unit_distribution_2d ( const float* f, uint32_t nx, uint32_t ny
     hipLaunchKernelGGL ( k_dist_rows, UNIT_GRID ( ny ), 0, 0, f, nx, ny, cdf, integrals, monotone );
     hipLaunchKernelGGL ( k_dist_marginal, dim3 ( 1 ), dim3 ( 64 ), 0, 0, ny, integrals, mcdf, monotone );
     if ( m > 0 ) hipLaunchKernelGGL ( k_dist_sample_2d, UNIT_GRID ( m ), 0, 0, f, cdf, nx, ny, integrals, mcdf, monotone, e12, m, xy2, pdf );
+    return hipGetLastError();
+}
+
+// ---- DevScene::sincos24: (cos, sin) of 2 * terra_PI * (k * 2^-24) for every 24-bit k, each entry by tdm_sincosf_pair itself (trace_device.h azimuth_fetch) ----
+__global__ __launch_bounds__ ( 256 ) void terra_sincos24_kernel ( float2* table ) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;          // grid = 2^24 / 256 blocks
+    float sn, cs;
+    tdm_sincosf_pair ( 2 * TERRA_PI_F * ( ( float ) k * 0x1p-24f ), sn, cs );
+    table[k] = make_float2 ( cs, sn );
+}
+hipError_t terra_fill_sincos24 ( float2* table, hipStream_t stream ) {
+    hipLaunchKernelGGL ( terra_sincos24_kernel, dim3 ( ( 1u << 24 ) / 256u ), dim3 ( 256 ), 0, stream, table );
     return hipGetLastError();
 }

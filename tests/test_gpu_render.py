@@ -510,8 +510,8 @@ def test_out_of_range_lds_resident_scene_keeps_the_leaf_box_cull(H, L, orc_lib, 
         want = H.Unit("orc").render_pixels(ref["d"], threads=8)       # (unshrunk) the oracle's image of the scaled box
         plain = render(2, integ)
         assert same(H, plain["pixels"], want["pixels"]) and np.array_equal(plain["calls"].reshape(want["rand_calls"].shape).astype(np.uint64), want["rand_calls"].astype(np.uint64)), integ
-    far = render(2, 0, cam_scale=12.0)           # 12 x (0, 100, -340): beyond 8 x the largest coordinate (340)
-    assert far["ti"][1] == 1 and far["ti"][2] == 1 and abs(far["ti"][4] - 8 * 340.0) < 1.0
+    far = render(2, 0, cam_scale=12.0)           # 12 x (0, 100, -340): beyond 8 x the largest VERTEX coordinate (200)
+    assert far["ti"][1] == 1 and far["ti"][2] == 1 and abs(far["ti"][4] - 8 * 200.0) < 1.0
     assert same(H, far["pixels"], render(0, 0, cam_scale=12.0)["pixels"]) and far["stats"]["tri_culled"] == 0
 
 

@@ -1,10 +1,11 @@
-"""rocprofv3 passes of the bench workloads -> profiles/r02_pmc.json + profiles/r02_rocprof_summary.md (run on the GPU box).
+"""rocprofv3 passes of the bench workloads -> <out>/<round>_pmc.json + <out>/<round>_rocprof_summary.md (run on the GPU box; copy both
+into profiles/ afterwards).
 
-    python3 tools/profile_r02.py [--only KEY_SUBSTRING] [--out gpurun_out/r02_prof]
+    python3 tools/profile_round.py [--round r03] [--only KEY_SUBSTRING] [--out gpurun_out/r03_prof]
 
 For every configuration below: one `--kernel-trace --stats` run and four separate `--pmc` runs (SQ group 1, SQ group 2,
 FETCH_SIZE, WRITE_SIZE; counters are never combined with tracing) of `python3 bench.py <args> --no-cpu-baseline
---no-workloads`. This script itself never touches the GPU: every run is a child process with the program right after `--`.
+--no-workloads --no-host-api`. This script itself never touches the GPU: every run is a child process with the program right after `--`.
 The JSON it writes is what bench.py's `roofline` reads (keyed like bench.pmc_key); the markdown is the human summary.
 HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section).
 """
@@ -62,10 +63,11 @@ def counters(directory):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
-    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r02_prof"))
+    ap.add_argument("--round", default="r03")
+    ap.add_argument("--out", default="")
     a = ap.parse_args()
-    out = Path(a.out); out.mkdir(parents=True, exist_ok=True)
-    jpath = out / "r02_pmc.json"
+    out = Path(a.out or str(ROOT / "gpurun_out" / f"{a.round}_prof")); out.mkdir(parents=True, exist_ok=True)
+    jpath = out / f"{a.round}_pmc.json"
     result = json.loads(jpath.read_text()) if jpath.exists() else {}
     md = []
     digest = bench.source_digest()
@@ -74,7 +76,7 @@ def main():
         if a.only and a.only not in key:
             continue
         tag = key.replace("|", "_").replace("=", "-")
-        args = ["bench.py", "--workload", wl, "--tree", tree, "--sample-split", str(split), "--no-cpu-baseline", "--no-workloads"] + extra
+        args = ["bench.py", "--workload", wl, "--tree", tree, "--sample-split", str(split), "--no-cpu-baseline", "--no-workloads", "--no-host-api"] + extra
         d = out / tag; d.mkdir(exist_ok=True)
         print("==", key, flush=True)
         rc, so = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d / "trace"), "--", "python3"] + args, d / "trace.err")
@@ -137,7 +139,7 @@ def main():
             if "terra_render_kernel" not in k and "FETCH_SIZE" in v:
                 md.append(f"(other kernel {k.split('(')[0]}: FETCH_SIZE {v.get('FETCH_SIZE', 0):.1f} KB, WRITE_SIZE {v.get('WRITE_SIZE', 0):.1f} KB per launch)")
         md.append("")
-        (out / "r02_rocprof_summary.md").write_text("# rocprofv3 summaries, round 2 (tools/profile_r02.py; source digest " + digest + ")\n\n" + "\n".join(md))
+        (out / f"{a.round}_rocprof_summary.md").write_text(f"# rocprofv3 summaries, round {a.round} (tools/profile_round.py; source digest " + digest + ")\n\n" + "\n".join(md))
     print("wrote", jpath)
 
 

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 hipError_t terra_launch_render ( const DevRenderParams&, hipStream_t ) { return hipErrorNoDevice; }
+hipError_t terra_fill_sincos24 ( float2*, hipStream_t ) { return hipErrorNoDevice; }
+bool       terra_render_wants_queue ( const DevRenderParams& ) { return false; }
 uint32_t   terra_render_blocks ( const DevRenderParams& ) { return 0; }
 hipError_t terra_launch_resolve ( const DevRenderParams&, hipStream_t ) { return hipErrorNoDevice; }
 bool       terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int ) { return n_nodes * 64 + n_tris * 112 < 8192; }
