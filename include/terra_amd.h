@@ -132,6 +132,17 @@ int  terra_amd_get_sample_split ( HTerraScene scene );
 int  terra_amd_set_environment_lighting ( HTerraScene scene, int on );
 int  terra_amd_get_environment_lighting ( HTerraScene scene );
 
+/* Sampler integration, off by default, PARITY UNPINNED. The reference constructs a stratified or Halton "hemisphere sampler" per pixel
+   (src/Terra.c:535-548) and never draws from it; only the stratified method's spp round-up has an effect. With on = 1 and one of those two sampling methods,
+   camera sample n of a pixel (n counts the samples the pixel has received, across calls) takes element n of that sampler -- Halton: the radical-inverse pair
+   (base 3, base 2) of n (src/Terra.c:734-755); stratified: `strata` x `strata` strata, 16 samples per stratum, element n mod (strata^2 * 16), the two offsets
+   drawn from the pixel's camera stream as terra_sampler_stratified_next_pair does (src/Terra.c:714-723) -- and uses it as the first two variates of the BSDF
+   sample at bounce 0 (src/Terra.c:1068-1071). Stream B is consumed as always; later bounces, light samples and MIS's own BSDF sample are untouched. The wiring
+   is this library's definition (the oracle's orc_set_sampler_integration restates it; device == oracle bit for bit); there is nothing in the reference to pin
+   it to. A launch parameter: no commit needed. With the switch off every image is the reference's. */
+int  terra_amd_set_sampler_integration ( HTerraScene scene, int on );
+int  terra_amd_get_sampler_integration ( HTerraScene scene );
+
 /* Work counters of the device path, summed over all launches since the last
    reset. They define the algorithmic bytes of the roofline:
    bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels. */

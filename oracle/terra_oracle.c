@@ -96,6 +96,7 @@ typedef struct {
     bool         dirty_objects, dirty_lights;
     uint64_t     frame_seed;
     int          env_lighting;   /* extension, off by default: see orc_set_environment_lighting */
+    int          sampler_integration;   /* extension, off by default: see orc_set_sampler_integration */
 } OrcScene;
 
 typedef struct { v3 origin, direction, inv_direction; } OrcRay;            /* reference src/TerraPrivate.h:107-111 */
@@ -1075,7 +1076,9 @@ static v3 integrate ( const OrcScene* s, const OrcRay* ray, const TerraObject* o
 /* ------------------------------------------------------------------------- */
 /* A3: terra_trace (reference src/Terra.c:1039-1097)                           */
 /* ------------------------------------------------------------------------- */
-static v3 trace ( const OrcScene* s, const OrcRay* primary ) {
+/* first_pair (extension, NULL = the reference's behaviour): the pixel sampler's pair for this camera sample; it replaces the first two variates handed to
+   bsdf.sample at bounce 0 (orc_set_sampler_integration). Stream B is consumed exactly as without it. */
+static v3 trace ( const OrcScene* s, const OrcRay* primary, const float* first_pair ) {
     v3 Lo = v3_set ( 0, 0, 0 ), throughput = v3_set ( 1, 1, 1 );
     OrcRay ray = *primary;
     for ( size_t bounce = 0; bounce <= s->opts.bounces; ++bounce ) {
@@ -1093,6 +1096,7 @@ static v3 trace ( const OrcScene* s, const OrcRay* primary ) {
         v3 wo = v3_neg ( ray.direction );
         Lo = v3_add ( Lo, integrate ( s, &ray, obj, &sf, p, wo, throughput, bounce ) );
         float e0 = randf(), e1 = randf(), e2 = randf();
+        if ( bounce == 0 && first_pair ) { e0 = first_pair[0]; e1 = first_pair[1]; }
         v3 wi = obj->material.bsdf.sample ( &sf, e0, e1, e2, &wo );
         float pdf = sel_max ( obj->material.bsdf.pdf ( &sf, &wi, &wo ), terra_Epsilon );    /* eps -> 1e-4f at the call */
         v3 f = obj->material.bsdf.eval ( &sf, &wi, &wo );
@@ -1111,7 +1115,7 @@ TerraFloat3 orc_trace_one ( HTerraScene h, const TerraFloat3* o, const TerraFloa
     tls.streamB.state = stateB; tls.streamB.inc = incB;
     uint64_t before = tls.c.rand_calls;
     OrcRay r = make_ray ( *o, *d );
-    v3 L = trace ( ( OrcScene* ) h, &r );
+    v3 L = trace ( ( OrcScene* ) h, &r, NULL );
     if ( rand_calls ) *rand_calls = ( uint32_t ) ( tls.c.rand_calls - before );
     return L;
 }
@@ -1185,7 +1189,24 @@ void orc_render_pixels ( const TerraCamera* cam, HTerraScene h, const TerraFrame
             dir = m3_apply ( &rot, dir );
             OrcRay ray = make_ray ( cam->position, dir );
             ++tls.c.samples;
-            acc = v3_add ( acc, trace ( s, &ray ) );
+            /* Sampler integration (extension; the reference constructs the pixel's stratified / Halton "hemisphere sampler" at src/Terra.c:535-548 and never
+               draws from it -- this wiring is this repo's definition, UNPINNED): camera sample number n = (samples already in the pixel) + k takes element n of
+               the pixel's sampler, right after r1, r2. Halton: the pair (radical inverse base 3, base 2) of n (src/Terra.c:734-755). Stratified: the sampler as
+               :542 builds it -- `strata` strata per dimension, 16 samples per stratum, sharing the pixel's camera stream -- at element n mod (strata^2 * 16)
+               (the reference asserts beyond that): stratum = m / 16, cell (stratum % strata, stratum / strata), offsets = the next two draws of stream A (:714-723). */
+            float pair[2]; const float* first_pair = NULL;
+            if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodHalton ) {
+                const uint64_t n = ( uint64_t ) ( uint32_t ) part->samples + k;
+                pair[0] = orc_radical_inverse ( 3, n ); pair[1] = orc_radical_inverse ( 2, n ); first_pair = pair;
+            } else if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodStratified && s->opts.strata > 0 ) {
+                const uint64_t strata = s->opts.strata, cap = strata * strata * 16;
+                const uint64_t m = ( ( uint64_t ) ( uint32_t ) part->samples + k ) % cap, stratum = m / 16;
+                const float stratum_size = 1.f / ( float ) strata, top = ( float ) ( 1.f - terra_Epsilon );
+                const float a = ( ( float ) ( stratum % strata ) + pcgA_nextf ( &A ) ) * stratum_size;
+                const float b = ( ( float ) ( stratum / strata ) + pcgA_nextf ( &A ) ) * stratum_size;
+                pair[0] = sel_min ( a, top ); pair[1] = sel_min ( b, top ); first_pair = pair;
+            }
+            acc = v3_add ( acc, trace ( s, &ray, first_pair ) );
         }
         if ( rand_calls ) rand_calls[pix] = ( uint32_t ) ( tls.c.rand_calls - before );
         part->acc = v3_add ( acc, part->acc );
@@ -1223,6 +1244,7 @@ void orc_render ( const TerraCamera* cam, HTerraScene h, const TerraFramebuffer*
 }
 void orc_set_frame_seed ( HTerraScene h, uint64_t seed ) { ( ( OrcScene* ) h )->frame_seed = seed; }
 void orc_set_environment_lighting ( HTerraScene h, int on ) { ( ( OrcScene* ) h )->env_lighting = on != 0; }
+void orc_set_sampler_integration ( HTerraScene h, int on ) { ( ( OrcScene* ) h )->sampler_integration = on != 0; }
 
 /* ------------------------------------------------------------------------- */
 /* scene lifecycle (reference src/Terra.c:130-282)                             */

@@ -69,6 +69,10 @@ void     orc_set_frame_seed ( HTerraScene scene, uint64_t seed );
 /* extension mirrored from terra_amd_set_environment_lighting(): a ray that leaves the scene adds
    throughput * environment (the line the reference has commented out, src/Terra.c:1056). Off by default. */
 void     orc_set_environment_lighting ( HTerraScene scene, int on );
+/* Extension, off by default, UNPINNED (the reference never draws from the pixel sampler it constructs, src/Terra.c:535-548): with on = 1 and the Halton or
+   stratified sampling method, camera sample n of a pixel takes element n of the pixel's sampler and uses it as the first two variates of the BSDF sample at
+   bounce 0. The product's switch of the same name (terra_amd_set_sampler_integration) does the same, bit for bit. */
+void     orc_set_sampler_integration ( HTerraScene scene, int on );
 
 /* work counters accumulated by every raycast since the last reset (thread-safe sums) */
 typedef struct {

@@ -136,6 +136,8 @@ struct DevScene {
 #define TERRA_KIND_ENV 16
 // ... and the bit that compiles textured-attribute sampling into terra_surface_init's counterpart
 #define TERRA_KIND_TEX 32
+// ... and the bit that compiles the sampler integration in (terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce)
+#define TERRA_KIND_SAMPLER 64
 
 // indices into the device counter array (uint64 each); mirrors TerraAmdStats
 enum { kCtrRays = 0, kCtrNodes, kCtrBoxTests, kCtrTriTests, kCtrHits, kCtrSamples, kCtrRandCalls, kCtrAttrFetches, kCtrPixels, kCtrLaunches, kCtrFaults, kCtrTriCulled,
@@ -190,4 +192,7 @@ struct DevRenderParams {
     int32_t  count_level;           // 1 lean, 2 full (see trace_device.h randf)
     uint32_t bsdf_kinds;            // mask of DevBsdfKind present in the scene (bit k = kind k)
     uint32_t leaf_cull;             // 1: skip the triangle test of a leaf child whose box the ray misses (Tracer::cull); host decides per call
+    // sampler integration (terra_amd_set_sampler_integration; compiled into the KINDS & TERRA_KIND_SAMPLER variants only): 0 off, 1 Halton, 2 stratified
+    // (`sampler_strata` strata per dimension, 16 samples per stratum: the sampler the reference constructs at src/Terra.c:542)
+    uint32_t sampler_mode, sampler_strata;
 };

@@ -7,7 +7,7 @@ hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream );
 bool       terra_render_wants_queue ( const DevRenderParams& p );   // the launch's loop gains from the persistent grid + job queue (render_kernels.hip "jobs")
 uint32_t   terra_render_blocks ( const DevRenderParams& p );   // 256-thread blocks of one chunk (own tiles x blocks per tile)
 hipError_t terra_launch_resolve ( const DevRenderParams& p, hipStream_t stream );   // second kernel of a split render (p.split > 1)
-bool       terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack );   // whole scene staged per block (the small-scene kernels)
+bool       terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack, uint32_t n_objects, uint32_t n_lights );   // whole scene staged per block (the small-scene kernels)
 void       terra_plan_lds ( DevRenderParams& p );     // fills stack_depth / lds_nodes / lds_tris / lds_mode
 void       terra_plan_fast_tree ( DevRenderParams& p );     // the plan of a fast-tree (MODE 2) launch: stack from the tree's depth, an LDS-staged node prefix
 hipError_t terra_launch_tiles ( bool pack, float* pixels, void* results, uint32_t fb_w, uint32_t x, uint32_t y, uint32_t w, uint32_t h,

@@ -63,7 +63,11 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     float4* ln = lds;                                                // byte offset 0: a staged node's address is its stack word
     float4* lt = ln + ( MODE == 2 ? 4 : TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;      // MODE 2 stages a prefix of the fast tree as plain 64-B nodes
     float4* lp = lt + 3 * lds_tris;
-    int* words = reinterpret_cast<int*> ( lp + 4 * lds_tris );
+    // MODE 1 also stages what shading reads per hit: the materials, the light list and the per-triangle areas (scene_extra_lds_bytes: three 16-byte aligned sections)
+    uint32_t* lm = reinterpret_cast<uint32_t*> ( lp + 4 * lds_tris );
+    const uint32_t m_words = MODE == 1 ? ( ( sc.n_objects * ( uint32_t ) ( sizeof ( DevMaterial ) / 4 ) + 3u ) & ~3u ) : 0u, l_words = MODE == 1 ? sc.n_lights * 4u : 0u, a_words = MODE == 1 ? ( ( sc.n_tris + 3u ) & ~3u ) : 0u;
+    uint32_t* ll = lm + m_words; uint32_t* la = ll + l_words;
+    int* words = reinterpret_cast<int*> ( la + a_words );
     T.stack = words + tid;
     T.leaves = words + stack_depth * TERRA_COL + tid;
     T.leaf_cap = ( int ) leaf_cap;
@@ -90,6 +94,13 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     }
     for ( uint32_t i = tid; i < 3 * lds_tris; i += TERRA_COL ) lt[i] = gt[i];
     for ( uint32_t i = tid; i < 4 * lds_tris; i += TERRA_COL ) lp[i] = gp[i];
+    if ( MODE == 1 ) {
+        const uint32_t* gm = reinterpret_cast<const uint32_t*> ( sc.mats ); const uint32_t* gl = reinterpret_cast<const uint32_t*> ( sc.lights ); const uint32_t* ga = reinterpret_cast<const uint32_t*> ( sc.tri_area );
+        for ( uint32_t i = tid; i < sc.n_objects * ( uint32_t ) ( sizeof ( DevMaterial ) / 4 ); i += TERRA_COL ) lm[i] = gm[i];
+        for ( uint32_t i = tid; i < sc.n_lights * 4u; i += TERRA_COL ) ll[i] = gl[i];
+        for ( uint32_t i = tid; i < sc.n_tris; i += TERRA_COL ) la[i] = ga[i];
+    }
+    T.l_mats = MODE == 1 ? reinterpret_cast<const DevMaterial*> ( lm ) : sc.mats; T.l_lights = MODE == 1 ? reinterpret_cast<const DevLight*> ( ll ) : sc.lights; T.l_area = MODE == 1 ? reinterpret_cast<const float*> ( la ) : sc.tri_area;
     T.l_nodes = ln; T.l_tris = reinterpret_cast<const float*> ( lt ); T.l_props = lp;
     T.lds_nodes = lds_nodes; T.lds_tris = lds_tris;
     __syncthreads();
@@ -300,7 +311,7 @@ TD void deposit ( float* acc_lds, V3 Lo ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_
 // launch leaves idle, because a wave's cost is the sum over its iterations of the LONGEST lane's node and leaf loops, and a wave that ramps down with few live lanes
 // runs short loops: with the queue the lanes of the Cornell frame are 97.5 % alive instead of 87 %, yet the frame needs as many node-loop iterations (4.5e8),
 // leaf-loop iterations and shading executions as before (profiles/r03_measurements/phase_cornell_queue.log, ab_job_queue.log).
-struct Jobs { uint32_t px, py, s; bool exhausted; };
+struct Jobs { uint32_t px, py, s; bool exhausted; uint32_t base; };      // base: camera samples the pixel has received before this job (sampler integration only)
 
 #ifndef TERRA_JOB_FETCH_MIN      // (coupled loop) lanes at a job boundary switch jobs together once this many wait there -- or no lane of the wave is tracing:
 #define TERRA_JOB_FETCH_MIN 1    // the switch (pixel decode, stream keys: ~250 instructions) then runs for several lanes at once. 1 measured best (Cornell: 1 -> 71.5 ms,
@@ -379,7 +390,7 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
     rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) j.py * p.fb_w + j.px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     aux[0] = 0.f; aux[256] = 0.f; aux[512] = 0.f; auxu[768] = job;
     if ( COUNT == 2 ) auxu[1024] = c.rand_calls;
-    j.s = 0;
+    j.s = 0; j.base = ( uint32_t ) prior_samples + chunk * p.chunk_spp;
 }
 
 template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
@@ -394,7 +405,8 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     Counters c = counters_zero();
     float* acc_lds = reinterpret_cast<float*> ( T.stack - tid ) + ( p.stack_depth + p.leaf_cap ) * TERRA_COL + tid;     // the parked words follow the leaf list
     job_init_lane ( p, acc_lds );       // (make_tracer's barrier came before; a wave only ever touches its own pool words)
-    Jobs jb; jb.px = jb.py = 0; jb.s = p.chunk_spp; jb.exhausted = false;
+    Jobs jb; jb.px = jb.py = 0; jb.s = p.chunk_spp; jb.exhausted = false; jb.base = 0;
+    SamplerPair sp = sampler_pair_none();       // (lives only in the KINDS & TERRA_KIND_SAMPLER variants)
     V3 Lo = v3 ( 0, 0, 0 ), throughput = v3 ( 1, 1, 1 );
     Ray ray = make_ray ( v3 ( 0, 0, 0 ), v3 ( 0, 0, 1 ) );
     uint32_t bounce = 0;
@@ -440,7 +452,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Ray ray_a;
                         pend = mis_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
                         b_o = point + sf.normal * 0.0001f;        // surface_ray ( sf, point, bsdf_dir, 1.f ) without the divisions
-                        cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
+                        cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d, sp );
                         cont_o = point + sf.normal * 0.0001f;     // (the divisions of surface_ray are redone when the ray starts)
                         ro = ray_a.o; rd = ray_a.d; job = 1; start = true;
                     } else {
@@ -453,6 +465,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                         ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                        if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) sp = sampler_pair_draw ( p.sampler_mode, p.sampler_strata, ( uint64_t ) jb.base + jb.s, rs.a );
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; job = 0; start = true;
                     }
                 }
@@ -491,7 +504,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         V3 wo = neg ( ray.d );
                         Ray shadow_ray;
                         pend = direct_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
-                        cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d );
+                        cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d, sp );
                         cont_o = point + sf.normal * 0.0001f;     // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are taken when the ray starts
                         ro = shadow_ray.o; rd = shadow_ray.d; shadow = true; start = true;
                     } else {
@@ -504,6 +517,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                         ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                        if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) sp = sampler_pair_draw ( p.sampler_mode, p.sampler_strata, ( uint64_t ) jb.base + jb.s, rs.a );
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; start = true;
                     }
                 }
@@ -526,7 +540,8 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 if ( have_ray ) {
                     if ( lt.best.tri != 0xffffffffu ) {
                         Surface sf;
-                        const PathDraws pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );       // (these integrators draw nothing themselves: the variates, and the table load, come first)
+                        PathDraws pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );       // (these integrators draw nothing themselves: the variates, and the table load, come first)
+                        if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) path_apply_sampler ( pd, sp, bounce );
                         V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
                         V3 wo = neg ( ray.d ), wi;
                         Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, point, wo, throughput, bounce, rs.b, c );
@@ -543,6 +558,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                         ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                        if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) sp = sampler_pair_draw ( p.sampler_mode, p.sampler_strata, ( uint64_t ) jb.base + jb.s, rs.a );
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; next = true;
                     }
                 }
@@ -565,6 +581,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 PS_WAVE ( c, kPsCamIter ); PS_LANE ( c, kPsCamLanes );
                 float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                 ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
+                if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) sp = sampler_pair_draw ( p.sampler_mode, p.sampler_strata, ( uint64_t ) jb.base + jb.s, rs.a );
                 Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++jb.s;
             }
         }
@@ -581,6 +598,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 V3 wo = neg ( ray.d ), wi;
                 Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
                 if ( !pre_draw ) pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );
+                if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) path_apply_sampler ( pd, sp, bounce );
                 end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                 if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }      // surface_ray ( sf, h.point, wi, 1.f ): its make_ray is the one at the top of this block
             } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
@@ -614,8 +632,13 @@ static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank
     return tiles > rank ? ( tiles - rank + world - 1 ) / world : 0;
 }
 
+// LDS a MODE-1 block spends on materials, lights and triangle areas (make_tracer): three sections, each a multiple of 16 bytes
+static size_t scene_extra_lds_bytes ( uint32_t n_objects, uint32_t n_lights, uint32_t n_tris ) {
+    return ( ( ( size_t ) n_objects * sizeof ( DevMaterial ) + 15 ) & ~size_t ( 15 ) ) + ( size_t ) n_lights * sizeof ( DevLight ) + ( ( ( size_t ) n_tris * 4 + 15 ) & ~size_t ( 15 ) );
+}
 size_t terra_lds_bytes ( const DevRenderParams& p ) {
-    return ( size_t ) ( p.stack_depth + p.leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) p.lds_nodes * ( p.lds_mode == 2 ? 64 : TERRA_LDS_NODE_BYTES ) + ( size_t ) p.lds_tris * ( 48 + 64 );
+    return ( size_t ) ( p.stack_depth + p.leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) p.lds_nodes * ( p.lds_mode == 2 ? 64 : TERRA_LDS_NODE_BYTES ) + ( size_t ) p.lds_tris * ( 48 + 64 )
+           + ( p.lds_mode == 1 ? scene_extra_lds_bytes ( p.scene.n_objects, p.scene.n_lights, p.scene.n_tris ) : 0 );
 }
 // fast tree (MODE 2): nodes of its breadth-first prefix staged per block. The kernel is latency bound (a ray's node fetches are a
 // dependent chain through L2 / Infinity Cache) and on the 97k-triangle hall the first 64 / 256 / 1024 nodes receive 39 / 57 / 70 % of
@@ -651,19 +674,19 @@ void terra_plan_fast_tree ( DevRenderParams& p ) {
 #define TERRA_LEAF_CAP_RESIDENT_MIN 8
 #endif
 // leaf-list entries an LDS-resident plan can afford (0 = the scene does not fit)
-static uint32_t resident_leaf_cap ( uint32_t n_nodes, uint32_t n_tris, int max_stack ) {
+static uint32_t resident_leaf_cap ( uint32_t n_nodes, uint32_t n_tris, int max_stack, uint32_t n_objects, uint32_t n_lights ) {
     const uint32_t depth = max_stack < 1 ? 1u : ( uint32_t ) max_stack;
-    const size_t fixed = ( size_t ) ( depth + TERRA_AUX_WORDS ) * 1024 + ( size_t ) n_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) n_tris * 112;
+    const size_t fixed = ( size_t ) ( depth + TERRA_AUX_WORDS ) * 1024 + ( size_t ) n_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) n_tris * 112 + scene_extra_lds_bytes ( n_objects, n_lights, n_tris );
     if ( fixed + ( size_t ) TERRA_LEAF_CAP_RESIDENT_MIN * 1024 > ( size_t ) TERRA_LDS_BUDGET ) return 0;
     const uint32_t cap = ( uint32_t ) ( ( ( size_t ) TERRA_LDS_BUDGET - fixed ) / 1024 );
     return cap > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : cap;
 }
-bool terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack ) { return resident_leaf_cap ( n_nodes, n_tris, max_stack ) != 0; }
+bool terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_stack, uint32_t n_objects, uint32_t n_lights ) { return resident_leaf_cap ( n_nodes, n_tris, max_stack, n_objects, n_lights ) != 0; }
 void terra_plan_lds ( DevRenderParams& p ) {
     uint32_t depth = p.scene.max_stack < 1 ? 1u : ( uint32_t ) p.scene.max_stack;
     p.stack_depth = depth;
     p.leaf_cap = TERRA_LEAF_CAP_MAX;
-    if ( const uint32_t cap = resident_leaf_cap ( p.scene.n_nodes, p.scene.n_tris, p.scene.max_stack ) ) {
+    if ( const uint32_t cap = resident_leaf_cap ( p.scene.n_nodes, p.scene.n_tris, p.scene.max_stack, p.scene.n_objects, p.scene.n_lights ) ) {
         p.lds_mode = 1; p.lds_nodes = p.scene.n_nodes; p.lds_tris = p.scene.n_tris; p.leaf_cap = cap;
         return;
     }
@@ -703,12 +726,13 @@ static hipError_t launch_kinds ( const DevRenderParams& p, size_t lds, hipStream
     return launch_instance<I, 2, MODE, KINDS> ( p, lds, stream );
 }
 // kinds present in the scene -> the leanest compiled variant that covers them: diffuse only (1), diffuse + Phong (3: what
-// OBJ/MTL scenes map to, satellite/src/Scene.cpp:193-230), or everything (GGX, glass, textures, environment term)
+// OBJ/MTL scenes map to, satellite/src/Scene.cpp:193-230), everything (GGX, glass, textures, environment term), or everything + the sampler integration
 template <int I, int MODE>
 static hipError_t launch_mode ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
     if ( p.bsdf_kinds == 1 ) return launch_kinds<I, MODE, 1> ( p, lds, stream );
     if ( ( p.bsdf_kinds & ~3u ) == 0 ) return launch_kinds<I, MODE, 3> ( p, lds, stream );
-    return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, lds, stream );
+    if ( ( p.bsdf_kinds & TERRA_KIND_SAMPLER ) == 0 ) return launch_kinds<I, MODE, TERRA_KINDS_ALL & ~TERRA_KIND_SAMPLER> ( p, lds, stream );      // (the sampler integration costs the generic
+    return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, lds, stream );                                                                            //  kernel 11 % when merely compiled in: its own variant)
 }
 template <int I>
 static hipError_t launch_one ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {

@@ -279,6 +279,7 @@ struct Scene {
     std::string tree_note;              // why the automatic mode chose what it chose
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
+    bool sampler_integration = false;   // terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce (a launch parameter)
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
     float test_shrink_reference_boxes = 0.f;       // terra_amd_debug_shrink_reference_boxes (tests only): the device copy of the reference tree's boxes is shrunk by this much
@@ -341,7 +342,7 @@ extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* 
     memset ( out, 0, sizeof *out );
     if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "scene not committed" );
     out->tree_mode = s->tree_mode; out->fast_tree = s->use_fast ? 1 : 0; out->fast_tree_built_on_device = s->fast_on_device ? 1 : 0; out->leaf_cull = ( s->cull_ok && !s->use_fast ) ? 1 : 0;
-    out->lds_resident = ( !s->use_fast && terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), s->dev.n_tris, s->max_stack ) ) ? 1 : 0;
+    out->lds_resident = ( !s->use_fast && terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), s->dev.n_tris, s->max_stack, ( uint32_t ) s->objects_pop, ( uint32_t ) s->lights.size() ) ) ? 1 : 0;
     out->max_coordinate = s->coord_max; out->max_coordinate_allowed = TERRA_CULL_MAX_COORD;
     out->last_call = s->last_call.load ( std::memory_order_relaxed ); out->camera_limit = ( s->reach || s->reach_cull ) ? s->reach_limit : TERRA_CULL_MAX_COORD;
     snprintf ( out->note, sizeof out->note, "%s", s->tree_note.c_str() );
@@ -359,6 +360,8 @@ extern "C" int terra_amd_set_environment_lighting ( HTerraScene h, int on ) {
     return 0;
 }
 extern "C" int terra_amd_get_environment_lighting ( HTerraScene h ) { return S ( h )->env_lighting ? 1 : 0; }
+extern "C" int terra_amd_set_sampler_integration ( HTerraScene h, int on ) { S ( h )->sampler_integration = on != 0; return 0; }
+extern "C" int terra_amd_get_sampler_integration ( HTerraScene h ) { return S ( h )->sampler_integration ? 1 : 0; }
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
 extern "C" uint64_t terra_amd_get_frame_seed ( HTerraScene h ) { return S ( h )->frame_seed; }
 
@@ -674,7 +677,7 @@ static int upload_scene ( Scene* s ) {
     for ( size_t j = 0; j < nobj && margin_ok; ++j ) margin_ok = coords_within_margin ( &s->objects[j].triangles[0].a.x, s->objects[j].triangles_count * 9 );
     bool coords_finite = true;
     for ( size_t j = 0; j < nobj; ++j ) for ( size_t i = 0; i < s->objects[j].triangles_count * 9; ++i ) { float v = fabsf ( ( &s->objects[j].triangles[0].a.x ) [i] ); if ( v > s->coord_max ) s->coord_max = v; if ( !std::isfinite ( v ) ) coords_finite = false; }
-    const bool resident = terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack );
+    const bool resident = terra_scene_fits_lds ( ( uint32_t ) s->nodes.size(), ( uint32_t ) ntri, s->max_stack, ( uint32_t ) nobj, ( uint32_t ) s->lights.size() );
     const bool hooked = s->test_shrink_reference_boxes > 0.f;      // the containment proof below ran on the unshrunk boxes: no shortcut that rests on it
     bool auto_ok = false;
     if ( s->tree_mode == 2 ) {
@@ -1040,6 +1043,10 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     s->last_call.store ( p.lds_mode == 2 ? ( s->dev.reach ? kTerraAmdCallFastTreeReach : kTerraAmdCallFastTree ) : ( p.leaf_cull ? kTerraAmdCallLeafCull : kTerraAmdCallReplica ), std::memory_order_relaxed );
     // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;
+    p.sampler_mode = 0; p.sampler_strata = ( uint32_t ) s->opts.strata;
+    if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodHalton ) p.sampler_mode = 1;
+    if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodStratified && s->opts.strata > 0 ) p.sampler_mode = 2;
+    if ( p.sampler_mode ) p.bsdf_kinds |= TERRA_KIND_SAMPLER;
     p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;
     p.lean_attr_per_hit = s->uniform_attr_count >= 0 ? ( uint32_t ) s->uniform_attr_count + 1 : 0;
     return 0;

@@ -21,6 +21,7 @@
 #include "dev_types.h"
 #include "dev_math.h"
 #include "rng.h"
+#include "sampling_device.h"
 
 #define TD __device__ __forceinline__
 
@@ -233,6 +234,9 @@ struct Tracer {
     const float4* l_nodes;     // LDS copies (valid for index < lds_nodes / lds_tris)
     const float*  l_tris;
     const float4* l_props;
+    const DevMaterial* l_mats;  // materials, lights, per-triangle areas: the block's LDS copies in MODE 1, the arrays in HBM otherwise (make_tracer)
+    const DevLight*    l_lights;
+    const float*       l_area;
     uint32_t      lds_nodes, lds_tris;
     int*          stack;       // this thread's column
     int*          leaves;
@@ -705,7 +709,7 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
     float w = 1 - u - v;
     V3 na = v3 ( p0.x, p0.y, p0.z ), nb = v3 ( p0.w, p1.x, p1.y ), nc = v3 ( p1.z, p1.w, p2.x );
     sf.normal = normalize ( ( nc * v + nb * u ) + na * w );
-    const DevMaterial& m = T.sc.mats[object];
+    const DevMaterial& m = T.l_mats[object];
     sf.emissive = v3p ( m.emissive );
     #pragma unroll
     for ( int i = 0; i < 4; ++i ) sf.attr[i] = v3p ( m.attributes[i] );
@@ -918,7 +922,7 @@ TD V3 glass_eval ( const Surface& sf, V3 wi ) {
 // BSDF dispatch. KINDS is a compile-time mask of the preset kinds present in the committed scene
 // (bit k = DevBsdfKind k): a diffuse-only scene compiles to straight-line diffuse code, which is
 // what keeps the Simple kernel inside 96 VGPRs (5 waves/SIMD) without scratch.
-#define TERRA_KINDS_ALL 63
+#define TERRA_KINDS_ALL 127
 // az: the azimuth of the SECOND variate (e2), if its table entry was fetched (azimuth_fetch) -- what the diffuse and GGX samplers and Phong's diffuse branch use
 template <int KINDS>
 TD V3 bsdf_sample ( Surface& sf, float e1, float e2, float e3, V3 wo, const Azimuth& az ) {
@@ -962,7 +966,7 @@ TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c, c
     double xl = ( double ) e * ( double ) sc.n_lights;
     uint32_t li = xl < 0 ? 0u : ( uint32_t ) xl;
     ls.pick_pdf = 1.f / ( float ) sc.lights_triangles_count;
-    DevLight l = sc.lights[li];
+    DevLight l = ( MODE == 1 && T ) ? T->l_lights[li] : sc.lights[li];
     float e_t = randf ( rb, c, COUNT );
     uint32_t k = ( uint32_t ) ( e_t * ( float ) l.tri_count );
     if ( k >= l.tri_count ) k = l.tri_count - 1;
@@ -995,7 +999,7 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
         float cosv = dot ( neg ( wi ), ls.norm );
         if ( cosv > 0 ) {
             V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
-            float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[h.tri] );
+            float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * T.l_area[h.tri] );
             V3 Ld = had ( lsf.emissive, f );
             Ld = Ld * ( dot ( wi, sf.normal ) / ( pdf * ls.pick_pdf ) );
             Lo = Lo + Ld;
@@ -1112,7 +1116,7 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
             float cosv = dot ( ls.norm, neg ( wi ) );
             if ( cosv > 0 ) {
                 float bpdf = bsdf_pdf<KINDS> ( sf, wi, wo );
-                float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[h.tri] );
+                float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * T.l_area[h.tri] );
                 if ( DEBUG_WEIGHTS ) {
                     float weight = ( bpdf * bpdf ) / ( lpdf * lpdf + bpdf * bpdf );
                     Lo = Lo + v3 ( 0, 0, weight );
@@ -1225,9 +1229,32 @@ TD bool path_continue ( Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, ui
     ++bounce;
     return bounce <= max_bounces;
 }
+// Sampler integration (terra_amd_set_sampler_integration, UNPINNED extension): at bounce 0 the pixel sampler's pair replaces the first two variates handed to
+// the BSDF's sampler; stream B has been consumed as always
+struct SamplerPair { float u0, u1; bool on; };
+TD SamplerPair sampler_pair_none() { SamplerPair s; s.u0 = s.u1 = 0.f; s.on = false; return s; }
+TD void path_apply_sampler ( PathDraws& d, const SamplerPair& sp, uint32_t bounce ) {
+    if ( sp.on && bounce == 0 ) { d.e0 = sp.u0; d.e1 = sp.u1; d.az = azimuth_none(); }
+}
+// element n of the pixel's sampler (n = camera samples the pixel has received before this one), as the oracle's orc_render_pixels takes it: Halton = the
+// radical-inverse pair of n (src/Terra.c:734-755); stratified = the sampler of src/Terra.c:542 at element n mod (strata^2 * 16), its two offsets the next draws of
+// the pixel's camera stream (src/Terra.c:714-723)
+TD SamplerPair sampler_pair_draw ( uint32_t mode, uint32_t strata, uint64_t n, Pcg32& stream_a ) {
+    SamplerPair s = sampler_pair_none();
+    if ( mode == 1 ) { s.u0 = radical_inverse ( 3, n ); s.u1 = radical_inverse ( 2, n ); s.on = true; }
+    else if ( mode == 2 && strata > 0 ) {
+        const uint64_t cap = ( uint64_t ) strata * strata * 16ull, m = n % cap, stratum = m / 16ull;
+        const float stratum_size = 1.f / ( float ) strata;
+        s.u0 = sd_below_one ( ( ( float ) ( uint32_t ) ( stratum % strata ) + trng_a_float ( stream_a ) ) * stratum_size );
+        s.u1 = sd_below_one ( ( ( float ) ( uint32_t ) ( stratum / strata ) + trng_a_float ( stream_a ) ) * stratum_size );
+        s.on = true;
+    }
+    return s;
+}
 template <int COUNT, int KINDS>
-TD bool path_continue ( const DevScene& sc, Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, uint32_t max_bounces, Pcg32& rb, Counters& c, V3& wi ) {
-    const PathDraws d = path_draw<COUNT> ( sc.sincos24, rb, c );
+TD bool path_continue ( const DevScene& sc, Surface& sf, V3 wo, V3& throughput, uint32_t& bounce, uint32_t max_bounces, Pcg32& rb, Counters& c, V3& wi, const SamplerPair& sp = sampler_pair_none() ) {
+    PathDraws d = path_draw<COUNT> ( sc.sincos24, rb, c );
+    if ( KINDS & TERRA_KIND_SAMPLER ) path_apply_sampler ( d, sp, bounce );
     return path_continue<KINDS> ( sf, wo, throughput, bounce, max_bounces, d, wi );
 }
 

@@ -6,7 +6,7 @@ hipError_t terra_fill_sincos24 ( float2*, hipStream_t ) { return hipErrorNoDevic
 bool       terra_render_wants_queue ( const DevRenderParams& ) { return false; }
 uint32_t   terra_render_blocks ( const DevRenderParams& ) { return 0; }
 hipError_t terra_launch_resolve ( const DevRenderParams&, hipStream_t ) { return hipErrorNoDevice; }
-bool       terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int ) { return n_nodes * 64 + n_tris * 112 < 8192; }
+bool       terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int, uint32_t, uint32_t ) { return n_nodes * 64 + n_tris * 112 < 8192; }
 void       terra_plan_lds ( DevRenderParams& ) {}
 hipError_t terra_launch_tiles ( bool, float*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float*, hipStream_t ) { return hipErrorNoDevice; }
 hipError_t terra_unit_pcg ( const uint32_t*, int, int, float* ) { return hipErrorNoDevice; }
