@@ -192,6 +192,7 @@ struct DevRenderParams {
     int32_t  count_level;           // 1 lean, 2 full (see trace_device.h randf)
     uint32_t bsdf_kinds;            // mask of DevBsdfKind present in the scene (bit k = kind k)
     uint32_t leaf_cull;             // 1: skip the triangle test of a leaf child whose box the ray misses (Tracer::cull); host decides per call
+    uint32_t fused_slab;            // 1: a cull launch inside the coordinate range: inner boxes may be decided with the fused slab arithmetic (Tracer::fused)
     // sampler integration (terra_amd_set_sampler_integration; compiled into the KINDS & TERRA_KIND_SAMPLER variants only): 0 off, 1 Halton, 2 stratified
     // (`sampler_strata` strata per dimension, 16 samples per stratum: the sampler the reference constructs at src/Terra.c:542)
     uint32_t sampler_mode, sampler_strata;

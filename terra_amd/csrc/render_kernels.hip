@@ -55,7 +55,7 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t
 #define TERRA_CHECK_SHRINK 0
 #endif
 template <int MODE>
-TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris, bool cull ) {
+TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, uint32_t leaf_cap, uint32_t lds_nodes, uint32_t lds_tris, bool cull, bool fused ) {
     const int tid = threadIdx.x;
     Tracer T;
     T.sc = sc;
@@ -73,7 +73,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.leaf_cap = ( int ) leaf_cap;
     T.stack_cap = ( int ) stack_depth - TERRA_CHECK_SHRINK;      // TERRA_CHECK_SHRINK > 0: positive control of the bounds check
     T.faults = nullptr;
-    T.cull = cull;
+    T.cull = cull; T.fused = cull && fused;
     const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
     const float4* gt = reinterpret_cast<const float4*> ( sc.tris );
     const float4* gp = reinterpret_cast<const float4*> ( sc.props );
@@ -397,7 +397,7 @@ template <int INTEGRATOR, int COUNT, int MODE, int KINDS>
 __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) ) void terra_render_kernel ( DevRenderParams p ) {
     extern __shared__ float4 lds_f4[];
     const int tid = threadIdx.x;
-    Tracer T0 = make_tracer<MODE> ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0 );
+    Tracer T0 = make_tracer<MODE> ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0, p.fused_slab != 0 );
     T0.faults = p.counters + kCtrFaults;
     const Tracer T = T0;
 

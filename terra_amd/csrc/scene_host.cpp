@@ -1036,6 +1036,7 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
         if ( s->fast_on_device ) p.lds_nodes = 0;      // the device-built tree is not numbered top-levels-first: nothing worth staging
     }
     p.leaf_cull = ( s->cull_ok && cam_ok && p.lds_mode != 2 ) ? 1u : 0u;
+    p.fused_slab = ( p.leaf_cull && !s->reach_cull ) ? 1u : 0u;      // (out of range only the rebuilt LEAF boxes carry a margin: the inner boxes are tested exactly as the reference tests them)
     // the azimuth table pays where VALU issue binds (LDS-resident scenes: Cornell Simple 65.8 -> 64.2 ms, Direct 145.2 -> 142.5); the kernels that wait on memory anyway
     // lose by one more dependent load per shaded hit (sphere scene 395 -> 419 ms, hall 282 -> 284; profiles/r03_measurements/ab_sincos_table.log)
     if ( p.lds_mode != 1 ) p.scene.sincos24 = nullptr;

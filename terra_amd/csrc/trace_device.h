@@ -248,6 +248,9 @@ struct Tracer {
     // unconditionally (src/TerraBVH.c:284-300); the closest hit is the same whenever a triangle the ray hits lies inside its
     // own +-1e-4 box as the slab test sees it, which the host verifies numerically at commit (terra_cull_margin_ok).
     bool cull;
+    // cull launches INSIDE the coordinate range may also decide the inner boxes with the fused slab arithmetic (slab_near_far_fused): the containment proof covers
+    // every box there. Outside it (Scene::reach_cull) only the rebuilt leaf boxes carry a margin; the inner boxes must be tested exactly as the reference tests them.
+    bool fused;
 };
 
 // -----------------------------------------------------------------------------
@@ -334,12 +337,19 @@ struct Closest { float depth; uint32_t tri; };
 #define TERRA_PUSH(T, sp, v) do { if ( TERRA_CHECK_BOUNDS && ( sp ) >= ( T ).stack + ( T ).stack_cap * TERRA_COL ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { *( sp ) = ( int ) ( v ); ( sp ) += TERRA_COL; } } while ( 0 )
 #define TERRA_LEAF(T, lp, v) do { if ( TERRA_CHECK_BOUNDS && ( lp ) >= ( T ).leaves + ( T ).leaf_cap * TERRA_COL ) { if ( ( T ).faults ) atomicAdd ( ( T ).faults, 1ull ); } else { *( lp ) = ( int ) ( v ); ( lp ) += TERRA_COL; } } while ( 0 )
 
-// which copy of each axis a lane reads from a staged node (byte offsets inside the node); regular rays only
-struct SlabSel { uint32_t x, y, z; };
+// which copy of each axis a lane reads from a staged node (byte offsets inside the node); regular rays only. oi = origin * inverse direction, for the
+// fused form of the slab test (slab_near_far_fused)
+struct SlabSel { uint32_t x, y, z; V3 oi; };
 TD SlabSel slab_sel ( const Ray& r ) {
     SlabSel s;
     s.x = r.inv.x < 0.f ? 16u : 0u; s.y = r.inv.y < 0.f ? 48u : 32u; s.z = r.inv.z < 0.f ? 80u : 64u;
+    s.oi = v3 ( r.o.x * r.inv.x, r.o.y * r.inv.y, r.o.z * r.inv.z );
     return s;
+}
+// regular AND every |inverse direction component| below 2^96: origin * inv cannot overflow for any origin the containment check admits
+TD bool ray_is_tame ( const Ray& r ) {
+    uint32_t ax = tdm_bits ( r.inv.x ) & 0x7fffffffu, ay = tdm_bits ( r.inv.y ) & 0x7fffffffu, az = tdm_bits ( r.inv.z ) & 0x7fffffffu;
+    return ax - 1u < 0x6f7fffffu && ay - 1u < 0x6f7fffffu && az - 1u < 0x6f7fffffu;
 }
 // slab test from (near, far) planes per axis: what slab<true> computes, without the per-axis min / max
 TD bool slab_near_far ( float nx, float fx, float ny, float fy, float nz, float fz, const Ray& r ) {
@@ -351,10 +361,24 @@ TD bool slab_near_far ( float nx, float fx, float ny, float fy, float nz, float 
     return tmax > __builtin_fmaxf ( tmin, 0.f );
 }
 
+// The same test with t = fma ( plane, inv, -(o * inv) ): one instruction per plane instead of two. NOT the reference's arithmetic -- (plane - o) * inv -- so only the
+// launches that need not reproduce the reference's traversal decision by decision may use it: the leaf-box-cull launches (Tracer::cull), whose commit-time proof
+// (scene_host.cpp "numeric containment check") only asks that every box test be CONSERVATIVE within the error budget: a triangle the ray hits must pass the test of
+// every box built around it. Here t carries two roundings -- of o * inv and of the fma -- worth u |o| + u |plane - o| in position, less than the three roundings of
+// the reference form the budget was drawn up for. Which nodes are visited beyond that may differ from the replica's by a few per billion (never the image).
+TD bool slab_near_far_fused ( float nx, float fx, float ny, float fy, float nz, float fz, const Ray& r, V3 oi ) {
+    float tnx = __builtin_fmaf ( nx, r.inv.x, -oi.x ), tfx = __builtin_fmaf ( fx, r.inv.x, -oi.x );
+    float tny = __builtin_fmaf ( ny, r.inv.y, -oi.y ), tfy = __builtin_fmaf ( fy, r.inv.y, -oi.y );
+    float tnz = __builtin_fmaf ( nz, r.inv.z, -oi.z ), tfz = __builtin_fmaf ( fz, r.inv.z, -oi.z );
+    float tmin = __builtin_fmaxf ( __builtin_fmaxf ( tnx, tny ), tnz );
+    float tmax = __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz );
+    return tmax > __builtin_fmaxf ( tmin, 0.f );
+}
+
 // one node of the reference traversal (src/TerraBVH.c:262-303): pop, slab-test both child boxes, push the inner children
 // that are hit, append the leaf children to the lane's list (all of them; with Tracer::cull only those whose box is hit).
 // An empty child slot (scenes with < 2 triangles) travels as a leaf and is dropped by leaf_step.
-template <int COUNT, int MODE, bool FAST>
+template <int COUNT, int MODE, bool FAST, bool FUSED = false>
 TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp, int*& lp, Counters& c ) {
     PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
     sp -= TERRA_COL;
@@ -366,8 +390,13 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
         child0 = cw.x; child1 = cw.y;
         if ( FAST ) {
             const float4 ax = *reinterpret_cast<const float4*> ( node + sel.x ), ay = *reinterpret_cast<const float4*> ( node + sel.y ), az = *reinterpret_cast<const float4*> ( node + sel.z );
-            hit0 = slab_near_far ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r );
-            hit1 = slab_near_far ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r );
+            if ( FUSED ) {
+                hit0 = slab_near_far_fused ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r, sel.oi );
+                hit1 = slab_near_far_fused ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r, sel.oi );
+            } else {
+                hit0 = slab_near_far ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r );
+                hit1 = slab_near_far ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r );
+            }
         } else {
             const float4 ax = *reinterpret_cast<const float4*> ( node ), ay = *reinterpret_cast<const float4*> ( node + 32 ), az = *reinterpret_cast<const float4*> ( node + 64 );
             hit0 = slab<false> ( v3 ( ax.x, ay.x, az.x ), v3 ( ax.y, ay.y, az.y ), r );
@@ -418,7 +447,7 @@ TD void leaf_step ( const Tracer& T, const int* entry, const RayState& st, V3 o_
     if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
 }
 
-template <int COUNT, int MODE, bool FAST>
+template <int COUNT, int MODE, bool FAST, bool FUSED = false>
 TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
     const SlabSel sel = slab_sel ( r );
     int* sp = T.stack; int* lp = T.leaves;
@@ -426,7 +455,7 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     *sp = 0; sp += TERRA_COL;                                          // the root: node 0 = byte offset 0
     for ( ;; ) {
         PS_WAVE ( c, kPsDrainIter );
-        while ( sp != T.stack && lp <= lp_full ) node_step<COUNT, MODE, FAST> ( T, r, sel, sp, lp, c );
+        while ( sp != T.stack && lp <= lp_full ) node_step<COUNT, MODE, FAST, FUSED> ( T, r, sel, sp, lp, c );
         for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) leaf_step<COUNT, MODE> ( T, e, st, o_perm, best, c );
         lp = T.leaves;
         if ( sp == T.stack ) break;
@@ -438,7 +467,11 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
     Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
     // the slab variant is chosen per WAVE: one irregular ray sends its whole wave down the exact path
-    if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true> ( T, r, st, o_perm, best, c );
+#ifndef TERRA_FUSED_SLAB
+#define TERRA_FUSED_SLAB 1
+#endif
+    if ( TERRA_FUSED_SLAB && MODE == 1 && T.fused && __all ( ray_is_tame ( r ) ) ) traverse_loops<COUNT, MODE, true, true> ( T, r, st, o_perm, best, c );
+    else if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true> ( T, r, st, o_perm, best, c );
     else traverse_loops<COUNT, MODE, false> ( T, r, st, o_perm, best, c );
     return best;
 }

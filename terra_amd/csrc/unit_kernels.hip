@@ -79,7 +79,7 @@ hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, c
 __device__ __forceinline__ Tracer unit_tracer ( const DevScene& sc, int* lds ) {
     Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.l_mats = sc.mats; T.l_lights = sc.lights; T.l_area = sc.tri_area; T.lds_nodes = 0; T.lds_tris = 0;
     T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.leaf_cap = TERRA_LEAF_CAP_MAX;
-    T.stack_cap = sc.max_stack < 1 ? 1 : sc.max_stack; T.faults = nullptr; T.cull = false;      // unit level: the reference's traversal decision by decision       // (unit kernels are not built with TERRA_CHECK_BOUNDS)
+    T.stack_cap = sc.max_stack < 1 ? 1 : sc.max_stack; T.faults = nullptr; T.cull = false; T.fused = false;      // unit level: the reference's traversal decision by decision       // (unit kernels are not built with TERRA_CHECK_BOUNDS)
     return T;
 }
 __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point ) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse_fast ( DevScene sc, int
     RayState s = ray_state_init ( r );
     Counters c = counters_zero();
     Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.l_mats = sc.mats; T.l_lights = sc.lights; T.l_area = sc.tri_area; T.lds_nodes = 0; T.lds_tris = 0;
-    T.stack = lds_stack + threadIdx.x; T.leaves = T.stack; T.leaf_cap = 0; T.stack_cap = sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack; T.faults = nullptr; T.cull = false;
+    T.stack = lds_stack + threadIdx.x; T.leaves = T.stack; T.leaf_cap = 0; T.stack_cap = sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack; T.faults = nullptr; T.cull = false; T.fused = false;
     ClosestRanked b = bvh_traverse_fast<1> ( T, r, s, c );
     bool f = b.tri != 0xffffffffu;
     found[i] = f ? 1 : 0;

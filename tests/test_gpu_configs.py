@@ -114,7 +114,8 @@ def test_config2_headline_launch_cornell_1080p_512spp_split8(H, L, orc_lib, devm
     rep = device_frame(L, d, split=8, tree_mode=0, calls=False)
     assert rep["traversal"] == "reference tree, replica traversal"
     assert H.same_bits(rep["acc"], got["acc"]) and H.same_bits(rep["pixels"], got["pixels"])
-    assert rep["stats"]["nodes"] == s["nodes"] and rep["stats"]["hits"] == s["hits"] and rep["stats"]["tri_tests"] > s["tri_tests"]
+    # (the cull launch's fused box test may decide a grazing box differently from the replica: node counts agree to parts per million; hits are the image's)
+    assert abs(rep["stats"]["nodes"] - s["nodes"]) <= 2e-5 * s["nodes"] and rep["stats"]["hits"] == s["hits"] and rep["stats"]["tri_tests"] > s["tri_tests"]
 
 
 _hall_want = {}
