@@ -226,6 +226,9 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 // bmin <= bmax, (b - o) * inv is monotone in b (both roundings are), increasing for inv > 0 and decreasing for inv < 0.
 // -----------------------------------------------------------------------------
 #define TERRA_LEAF_CAP_MAX 16
+#ifndef TERRA_ORDERED_LEAVES       // 1: fused launches drain their leaf lists nearest box first, culled by the closest hit (traverse_loops_ordered). Built, bit-identical
+#define TERRA_ORDERED_LEAVES 0     // (all GPU tests), 13 % fewer triangle tests on the Cornell frame -- and 62.9 -> 71.7 ms: its extra live state pushes the 96-register
+#endif                             // kernel into scratch (68 B, reloads inside the ray loop). profiles/r03_measurements/ab_ordered_leaves.log
 #define TERRA_COL 256              // stride of a stack / leaf-list column: the block's thread count
 #define TERRA_LDS_NODE_BYTES 112   // staged node (see above)
 
@@ -366,13 +369,14 @@ TD bool slab_near_far ( float nx, float fx, float ny, float fy, float nz, float 
 // (scene_host.cpp "numeric containment check") only asks that every box test be CONSERVATIVE within the error budget: a triangle the ray hits must pass the test of
 // every box built around it. Here t carries two roundings -- of o * inv and of the fma -- worth u |o| + u |plane - o| in position, less than the three roundings of
 // the reference form the budget was drawn up for. Which nodes are visited beyond that may differ from the replica's by a few per billion (never the image).
-TD bool slab_near_far_fused ( float nx, float fx, float ny, float fy, float nz, float fz, const Ray& r, V3 oi ) {
+TD bool slab_near_far_fused ( float nx, float fx, float ny, float fy, float nz, float fz, const Ray& r, V3 oi, float& t_enter ) {
     float tnx = __builtin_fmaf ( nx, r.inv.x, -oi.x ), tfx = __builtin_fmaf ( fx, r.inv.x, -oi.x );
     float tny = __builtin_fmaf ( ny, r.inv.y, -oi.y ), tfy = __builtin_fmaf ( fy, r.inv.y, -oi.y );
     float tnz = __builtin_fmaf ( nz, r.inv.z, -oi.z ), tfz = __builtin_fmaf ( fz, r.inv.z, -oi.z );
     float tmin = __builtin_fmaxf ( __builtin_fmaxf ( tnx, tny ), tnz );
     float tmax = __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz );
-    return tmax > __builtin_fmaxf ( tmin, 0.f );
+    t_enter = __builtin_fmaxf ( tmin, 0.f );
+    return tmax > t_enter;
 }
 
 // one node of the reference traversal (src/TerraBVH.c:262-303): pop, slab-test both child boxes, push the inner children
@@ -384,6 +388,7 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
     sp -= TERRA_COL;
     const uint32_t w = ( uint32_t ) * sp;
     uint32_t child0, child1; bool hit0, hit1;
+    float te0 = 0.f, te1 = 0.f;          // (FUSED) entry distance of each child box
     if ( MODE == 1 ) {
         const char* node = reinterpret_cast<const char*> ( T.l_nodes ) + w;          // w = byte offset of the staged node
         const uint2 cw = *reinterpret_cast<const uint2*> ( node + 96 );
@@ -391,8 +396,8 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
         if ( FAST ) {
             const float4 ax = *reinterpret_cast<const float4*> ( node + sel.x ), ay = *reinterpret_cast<const float4*> ( node + sel.y ), az = *reinterpret_cast<const float4*> ( node + sel.z );
             if ( FUSED ) {
-                hit0 = slab_near_far_fused ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r, sel.oi );
-                hit1 = slab_near_far_fused ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r, sel.oi );
+                hit0 = slab_near_far_fused ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r, sel.oi, te0 );
+                hit1 = slab_near_far_fused ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r, sel.oi, te1 );
             } else {
                 hit0 = slab_near_far ( ax.x, ax.y, ay.x, ay.y, az.x, az.y, r );
                 hit1 = slab_near_far ( ax.z, ax.w, ay.z, ay.w, az.z, az.w, r );
@@ -416,8 +421,15 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
     const bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
     if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, sp, child0 ); }
     if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, sp, child1 ); }
-    if ( leaf0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child0 & 0x7fffffffu ) ); }
-    if ( leaf1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child1 & 0x7fffffffu ) ); }
+    if ( FUSED && TERRA_ORDERED_LEAVES ) {
+        // ordered drain (traverse_loops_ordered): an entry = entry distance truncated to its upper 16 bits (never above the true one) | position in the list << 12 | triangle.
+        // Unsigned order of the words = nearest box first, then first met. (Only cull launches come here: a leaf whose box is missed is not listed.)
+        if ( leaf0 && hit0 ) { const uint32_t pos = ( uint32_t ) ( reinterpret_cast<const char*> ( lp ) - reinterpret_cast<const char*> ( T.leaves ) ) << 2; TERRA_LEAF ( T, lp, ( __float_as_uint ( te0 ) & 0xffff0000u ) | pos | ( child0 & 0xfffu ) ); }
+        if ( leaf1 && hit1 ) { const uint32_t pos = ( uint32_t ) ( reinterpret_cast<const char*> ( lp ) - reinterpret_cast<const char*> ( T.leaves ) ) << 2; TERRA_LEAF ( T, lp, ( __float_as_uint ( te1 ) & 0xffff0000u ) | pos | ( child1 & 0xfffu ) ); }
+    } else {
+        if ( leaf0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child0 & 0x7fffffffu ) ); }
+        if ( leaf1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child1 & 0x7fffffffu ) ); }
+    }
     if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( leaf0 && !hit0 ) + ( uint32_t ) ( leaf1 && !hit1 );
 }
 
@@ -462,6 +474,54 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     }
 }
 
+// Ordered, depth-culled drain of the leaf list -- for the launches whose boxes are covered by the containment proof (Tracer::fused: LDS-resident scene inside the
+// coordinate range, leaf-box cull on). The reference tests every leaf it meets and keeps the smallest depth, the first met among equals (src/TerraBVH.c:284-300).
+// A triangle's hit lies at least its box margin (1e-4, against ~1e-6 of rounding: the proof's budget) beyond the point where the ray enters that triangle's box,
+// so a leaf whose box is entered BEYOND the closest hit found so far cannot change the answer. Per drain: (1) the entry with the nearest box is tested first --
+// one test per lane, all lanes that hold a leaf together; (2) the list is compacted to the entries whose box is entered no later than that hit; (3) those are
+// tested. On the Cornell frame a ray through one of the boxes lists 6 leaves (entry face, exit face, the wall behind: two triangles each) and now tests 2.
+// Ties in depth go to the entry met first, as in the reference: every entry carries its position in the visit order.
+template <int COUNT>
+TD void leaf_step_packed ( const Tracer& T, uint32_t word, uint32_t drain, const RayState& st, V3 o_perm, Closest& best, uint32_t& best_vis, Counters& c ) {
+    PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
+    const uint32_t ti = word & 0xfffu, vis = ( drain << 4 ) | ( ( word >> 12 ) & 15u );
+    const int kx = st.ix, ky = st.iy, kz = st.iz;
+    const float* t = T.l_tris + 12 * ti;
+    float pa[3], pb[3], pc[3];
+    pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
+    pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
+    pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
+    if ( COUNT ) ++c.tri_tests;
+    float depth;
+    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && ( depth < best.depth || ( depth == best.depth && vis < best_vis ) ) ) { best.depth = depth; best.tri = ti; best_vis = vis; }
+}
+template <int COUNT>
+TD void traverse_loops_ordered ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
+    const SlabSel sel = slab_sel ( r );
+    int* sp = T.stack; int* lp = T.leaves;
+    int* const lp_full = T.leaves + ( T.leaf_cap - 2 ) * TERRA_COL;       // a node adds at most two leaves
+    *sp = 0; sp += TERRA_COL;
+    uint32_t best_vis = 0xffffffffu, drain = 0;
+    for ( ;; ) {
+        PS_WAVE ( c, kPsDrainIter );
+        while ( sp != T.stack && lp <= lp_full ) node_step<COUNT, 1, true, true> ( T, r, sel, sp, lp, c );
+        if ( lp != T.leaves ) {
+            uint32_t nearest = 0xffffffffu;
+            for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) { const uint32_t w = ( uint32_t ) * e; nearest = w < nearest ? w : nearest; }
+            leaf_step_packed<COUNT> ( T, nearest, drain, st, o_perm, best, best_vis, c );
+            int* keep = T.leaves;
+            for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) {
+                const uint32_t w = ( uint32_t ) * e;
+                if ( w != nearest && __uint_as_float ( w & 0xffff0000u ) <= best.depth ) { *keep = ( int ) w; keep += TERRA_COL; }
+                else if ( COUNT == 2 && w != nearest ) ++c.tri_culled;
+            }
+            for ( const int* e = T.leaves; e != keep; e += TERRA_COL ) leaf_step_packed<COUNT> ( T, ( uint32_t ) * e, drain, st, o_perm, best, best_vis, c );
+            lp = T.leaves; ++drain;
+        }
+        if ( sp == T.stack ) break;
+    }
+}
+
 template <int COUNT, int MODE>
 TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
     Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
@@ -470,7 +530,10 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 #ifndef TERRA_FUSED_SLAB
 #define TERRA_FUSED_SLAB 1
 #endif
-    if ( TERRA_FUSED_SLAB && MODE == 1 && T.fused && __all ( ray_is_tame ( r ) ) ) traverse_loops<COUNT, MODE, true, true> ( T, r, st, o_perm, best, c );
+    if ( TERRA_FUSED_SLAB && MODE == 1 && T.fused && __all ( ray_is_tame ( r ) ) ) {
+        if ( TERRA_ORDERED_LEAVES ) traverse_loops_ordered<COUNT> ( T, r, st, o_perm, best, c );
+        else traverse_loops<COUNT, MODE, true, true> ( T, r, st, o_perm, best, c );
+    }
     else if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true> ( T, r, st, o_perm, best, c );
     else traverse_loops<COUNT, MODE, false> ( T, r, st, o_perm, best, c );
     return best;
