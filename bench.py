@@ -362,7 +362,7 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     torch, dist, lib, dev = c.torch, c.dist, c.lib, c.dev
     world, rank = c.world, c.rank
     lib.clear_error()
-    scene = scenes.build_scene(lib, d, tree_mode=TREE_MODES[tree])
+    scene = scenes.build_scene(lib, d, tree_mode=TREE_MODES[tree], counters=False)      # the library's default: no work counters in the timed launches
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
     runtime.check(lib.set_sample_split(scene, split), "terra_amd_set_sample_split")
@@ -444,9 +444,15 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
-    launches = max(1, st["launches"])
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    # the work counters (rays, nodes, tests, hits: what the roofline's algorithmic bytes are made of) come from ONE EXTRA, untimed launch with the counters
+    # enabled (terra_amd_set_work_counters): they are instrumentation, off by default, and the timed launches above ran without them
+    runtime.check(lib.set_work_counters(scene, 1), "terra_amd_set_work_counters")
+    runtime.check(lib.reset_stats(scene))
+    step(); fence()
+    st = runtime.Stats(); runtime.check(lib.get_stats(scene, C.byref(st))); st = st.as_dict()
+    runtime.check(lib.set_work_counters(scene, 0), "terra_amd_set_work_counters")
+    launches = max(1, st["launches"])
 
     # per-rank phase breakdown (N > 1): where a step's time goes on every rank, so that a scaling shortfall can be attributed
     phases = None
@@ -472,7 +478,7 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     if check:
         # one extra LOW-SPP step through the same shard -> pack -> gather -> unpack path into a fresh frame must equal an unsharded render bit for bit (rank 0)
         dd = scenes.SceneDesc(**{**d.__dict__, "spp": max(split, min(d.spp, 4 * split))})
-        scene2 = scenes.build_scene(lib, dd, tree_mode=TREE_MODES[tree])
+        scene2 = scenes.build_scene(lib, dd, tree_mode=TREE_MODES[tree], counters=False)
         runtime.check(lib.set_sample_split(scene2, split), "terra_amd_set_sample_split")
         cur["scene"], cur["fb"] = scene2, runtime.DeviceFramebuffer(W, H, device=dev)
         fence(); step(); fence()
@@ -509,6 +515,7 @@ def result_block(d, name, tree, split, steps, warmup, world, m, spp_override, in
         out["mrays_per_s"] = round(st["rays"] * world / (m["kernel_ms"] * 1e-3) / 1e6, 1)
         out["roofline"] = roofline(pmc_key(name, tree, integrator_name, split, spp_override), st, m["kernel_ms"], m["lds_resident"], world)
         out["counters_per_launch"] = st
+        out["counters_note"] = "from one extra untimed launch with terra_amd_set_work_counters(scene, 1); the timed launches run without work counters (the library's default)"
     return out
 
 
@@ -523,7 +530,7 @@ def host_api(c, d, tree, split, steps):
     from terra_amd import api, runtime, scenes
     lib = c.lib
     lib.clear_error()
-    scene = scenes.build_scene(lib, d, tree_mode=TREE_MODES[tree]); cam = scenes.camera_of(d)
+    scene = scenes.build_scene(lib, d, tree_mode=TREE_MODES[tree], counters=False); cam = scenes.camera_of(d)
     fb = api.Framebuffer(lib, d.width, d.height)              # terra_framebuffer_create: pinned host memory
     samples = d.width * d.height * d.spp
     out = {"pcie_bytes_per_step": d.width * d.height * 44, "steps": steps}

@@ -145,7 +145,13 @@ int  terra_amd_get_sampler_integration ( HTerraScene scene );
 
 /* Work counters of the device path, summed over all launches since the last
    reset. They define the algorithmic bytes of the roofline:
-   bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels. */
+   bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels.
+   The device-side counters (rays, nodes, box_tests, tri_tests, hits, rand_calls, attr_fetches, tri_culled) are INSTRUMENTATION and off by default, like the
+   reference's TERRA_PROFILE (src/Terra.c:564,634,1643: compiled out unless defined): terra_amd_set_work_counters(scene, 1) makes subsequent render calls count
+   (a launch parameter, no commit needed), at 4-6 % of the render time; a call that is handed a per-pixel draw-count buffer counts regardless. samples, pixels
+   and launches are kept by the host either way. */
+int terra_amd_set_work_counters ( HTerraScene scene, int on );
+int terra_amd_get_work_counters ( HTerraScene scene );
 typedef struct {
     uint64_t rays;          /* terra_scene_raycast equivalents (src/Terra.c:1623) */
     uint64_t nodes;         /* BVH nodes popped (src/TerraBVH.c:267) */

@@ -187,9 +187,7 @@ struct DevRenderParams {
     // staged; leaf_cap deferred-leaf entries per thread; lds_mode 0 = nothing staged, 1 = whole scene
     uint32_t stack_depth, leaf_cap, lds_nodes, lds_tris;
     int32_t  lds_mode;
-    // lean counting (COUNT level 1): attribute fetches per hit (attributes_count + 1, identical for every material)
-    uint32_t lean_attr_per_hit;
-    int32_t  count_level;           // 1 lean, 2 full (see trace_device.h randf)
+    int32_t  count_level;           // work counters: 0 none (the default), 2 all six per lane (terra_amd_set_work_counters, or a per-pixel draw-count buffer was passed)
     uint32_t bsdf_kinds;            // mask of DevBsdfKind present in the scene (bit k = kind k)
     uint32_t leaf_cull;             // 1: skip the triangle test of a leaf child whose box the ray misses (Tracer::cull); host decides per call
     uint32_t fused_slab;            // 1: a cull launch inside the coordinate range: inner boxes may be decided with the fused slab arithmetic (Tracer::fused)

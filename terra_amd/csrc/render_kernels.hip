@@ -25,22 +25,15 @@
 
 struct DevResult { float acc[3]; int samples; };
 
-template <int COUNT>
-TD void wave_flush_counters ( const Counters& c, unsigned long long* g, uint32_t lean_attr_per_hit ) {
+TD void wave_flush_counters ( const Counters& c, unsigned long long* g ) {
     const uint32_t v[6] = { c.rays, c.nodes, c.tri_tests, c.hits, c.rand_calls, c.attr_fetches };
     const int slot[6] = { kCtrRays, kCtrNodes, kCtrTriTests, kCtrHits, kCtrRandCalls, kCtrAttrFetches };
     #pragma unroll
-    for ( int k = 0; k < ( COUNT == 2 ? 6 : 4 ); ++k ) {
+    for ( int k = 0; k < 6; ++k ) {
         unsigned long long x = v[k];
         #pragma unroll
         for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
-        if ( ( threadIdx.x & 63 ) == 0 && x ) {
-            atomicAdd ( &g[slot[k]], x );
-            if ( COUNT == 1 && k == 3 ) {       // lean: 4 stream-B draws and a fixed number of attribute fetches per hit
-                atomicAdd ( &g[kCtrRandCalls], 4 * x );
-                atomicAdd ( &g[kCtrAttrFetches], ( unsigned long long ) lean_attr_per_hit * x );
-            }
-        }
+        if ( ( threadIdx.x & 63 ) == 0 && x ) atomicAdd ( &g[slot[k]], x );
     }
 }
 
@@ -610,7 +603,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     }
     }
 
-    if ( COUNT ) wave_flush_counters<COUNT> ( c, p.counters, p.lean_attr_per_hit );
+    if ( COUNT ) wave_flush_counters ( c, p.counters );
     if ( COUNT == 2 && p.leaf_cull ) {
         unsigned long long x = c.tri_culled;
         for ( int off = 32; off > 0; off >>= 1 ) x += __shfl_xor ( x, off, 64 );
@@ -720,9 +713,9 @@ static hipError_t launch_instance ( const DevRenderParams& p, size_t lds, hipStr
 }
 template <int I, int MODE, int KINDS>
 static hipError_t launch_kinds ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
-    // lean counting is only valid for integrators without light sampling (every hit = 4 draws)
-    constexpr bool lean_ok = I == 0 || I == 3 || I == 4 || I == 5;
-    if ( lean_ok && p.count_level == 1 ) return launch_instance<I, lean_ok ? 1 : 2, MODE, KINDS> ( p, lds, stream );
+    // work counters are instrumentation, off unless asked for (terra_amd_set_work_counters / a per-pixel draw-count buffer): the counting kernels carry
+    // 4-7 more live registers per lane and cost the Cornell frame 6 % (59.3 vs 62.9 ms; profiles/r03_measurements/ab_counters.log)
+    if ( p.count_level == 0 ) return launch_instance<I, 0, MODE, KINDS> ( p, lds, stream );
     return launch_instance<I, 2, MODE, KINDS> ( p, lds, stream );
 }
 // kinds present in the scene -> the leanest compiled variant that covers them: diffuse only (1), diffuse + Phong (3: what

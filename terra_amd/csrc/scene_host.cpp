@@ -279,6 +279,7 @@ struct Scene {
     std::string tree_note;              // why the automatic mode chose what it chose
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
+    bool work_counters = false;         // terra_amd_set_work_counters: the render kernels count rays / nodes / tests / hits / draws (instrumentation, off by default)
     bool sampler_integration = false;   // terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce (a launch parameter)
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
@@ -360,6 +361,8 @@ extern "C" int terra_amd_set_environment_lighting ( HTerraScene h, int on ) {
     return 0;
 }
 extern "C" int terra_amd_get_environment_lighting ( HTerraScene h ) { return S ( h )->env_lighting ? 1 : 0; }
+extern "C" int terra_amd_set_work_counters ( HTerraScene h, int on ) { S ( h )->work_counters = on != 0; return 0; }
+extern "C" int terra_amd_get_work_counters ( HTerraScene h ) { return S ( h )->work_counters ? 1 : 0; }
 extern "C" int terra_amd_set_sampler_integration ( HTerraScene h, int on ) { S ( h )->sampler_integration = on != 0; return 0; }
 extern "C" int terra_amd_get_sampler_integration ( HTerraScene h ) { return S ( h )->sampler_integration ? 1 : 0; }
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
@@ -1042,14 +1045,12 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     if ( p.lds_mode != 1 ) p.scene.sincos24 = nullptr;
     // what this call runs (TerraAmdTraversalInfo::last_call): the commit-time decision can be overridden per call by the camera position
     s->last_call.store ( p.lds_mode == 2 ? ( s->dev.reach ? kTerraAmdCallFastTreeReach : kTerraAmdCallFastTree ) : ( p.leaf_cull ? kTerraAmdCallLeafCull : kTerraAmdCallReplica ), std::memory_order_relaxed );
-    // lean counters when draws and attribute fetches follow from the hit count (kernel decides per integrator)
     p.bsdf_kinds = s->bsdf_kinds;
     p.sampler_mode = 0; p.sampler_strata = ( uint32_t ) s->opts.strata;
     if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodHalton ) p.sampler_mode = 1;
     if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodStratified && s->opts.strata > 0 ) p.sampler_mode = 2;
     if ( p.sampler_mode ) p.bsdf_kinds |= TERRA_KIND_SAMPLER;
-    p.count_level = s->uniform_attr_count >= 0 ? 1 : 2;
-    p.lean_attr_per_hit = s->uniform_attr_count >= 0 ? ( uint32_t ) s->uniform_attr_count + 1 : 0;
+    p.count_level = s->work_counters ? 2 : 0;
     return 0;
 }
 

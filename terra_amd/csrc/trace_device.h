@@ -1045,9 +1045,7 @@ TD V3 bsdf_eval ( const Surface& sf, V3 wi, V3 wo ) {
 // -----------------------------------------------------------------------------
 // lights and integrators
 // -----------------------------------------------------------------------------
-// COUNT levels: 0 none; 1 lean = rays, nodes, tri_tests, hits per lane (draws and attribute fetches are then
-// derived from hits at flush time, valid when every hit is a main-path hit with 4 draws and all materials have the
-// same attribute count); 2 full = all six per lane
+// COUNT levels: 0 none (the default launch); 2 = rays, nodes, triangle tests, hits, stream-B draws, attribute fetches per lane
 TD float randf ( Pcg32& b, Counters& c, int count ) { if ( count == 2 ) ++c.rand_calls; return trng_b_float ( b ); }
 
 TD float triangle_area ( V3 a, V3 b, V3 cc ) { return length ( cross ( b - a, cc - a ) ) / 2; }

@@ -61,6 +61,8 @@ _EXTRA = {
     "terra_amd_get_device": (C.c_int, []),
     "terra_amd_set_frame_seed": (None, [C.c_void_p, C.c_uint64]),
     "terra_amd_debug_shrink_reference_boxes": (C.c_int, [C.c_void_p, C.c_float]),
+    "terra_amd_set_work_counters": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_get_work_counters": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sampler_integration": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_sampler_integration": (C.c_int, [C.c_void_p]),
     "terra_amd_get_frame_seed": (C.c_uint64, [C.c_void_p]),

@@ -451,16 +451,20 @@ def apply_options(lib: api.TerraLib, scene, d: SceneDesc) -> None:
     o.gamma = d.gamma
 
 
-def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode=None, tree_builder=None, debug_shrink=None):
+def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode=None, tree_builder=None, debug_shrink=None, counters=True):
     """Returns a committed HTerraScene (c_void_p value) owned by `lib`.
     tree_mode: terra_amd_set_tree_mode of the product (0 replica traversal of the reference tree, 1 fast tree, 2 automatic);
-    None leaves the library's default (automatic). The reference and the oracle only have the reference traversal."""
+    None leaves the library's default (automatic). The reference and the oracle only have the reference traversal.
+    counters: enable the product's work counters (terra_amd_set_work_counters; off by default in the library, on by default HERE because the tests and the
+    tools read terra_amd_get_stats); bench.py times with counters=False."""
     scene = lib.scene_create()
     if tree_mode is not None and lib.has("terra_amd_set_tree_mode"):
         f = lib.fn("terra_amd_set_tree_mode", C.c_int, [C.c_void_p, C.c_int])
         assert f(scene, tree_mode) == 0
     if tree_builder is not None and lib.has("terra_amd_set_tree_builder"):      # 0 host binned SAH, 1 device LBVH (the fast tree only)
         assert lib.fn("terra_amd_set_tree_builder", C.c_int, [C.c_void_p, C.c_int])(scene, tree_builder) == 0
+    if counters and lib.has("terra_amd_set_work_counters"):      # the product's work counters are off by default (instrumentation); tests and tools want them
+        lib.fn("terra_amd_set_work_counters", C.c_int, [C.c_void_p, C.c_int])(scene, 1)
     if debug_shrink:                # the product's test hook (terra_amd.h terra_amd_debug_shrink_reference_boxes)
         assert lib.fn("terra_amd_debug_shrink_reference_boxes", C.c_int, [C.c_void_p, C.c_float])(scene, float(debug_shrink)) == 0
     if d.environment_lighting:      # the reference has no such switch: its environment term never reaches the image

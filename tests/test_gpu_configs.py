@@ -59,12 +59,12 @@ def traversal_name(ti):
     return "reference tree, replica traversal"
 
 
-def device_frame(L, d, split=1, tree_mode=None, calls=True, shard=None):
+def device_frame(L, d, split=1, tree_mode=None, calls=True, shard=None, counters=True):
     """one terra_amd_render_device call over the whole frame; returns host copies + the launch's work counters.
     tree_mode None = the library default (2, automatic): what bench.py times with --tree auto"""
     import torch
     L.clear_error()
-    scene = scenes.build_scene(L, d, tree_mode=tree_mode)
+    scene = scenes.build_scene(L, d, tree_mode=tree_mode, counters=counters)
     assert runtime.last_error() == "", runtime.last_error()
     runtime.check(L.set_sample_split(scene, split), "terra_amd_set_sample_split")
     ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(scene, C.byref(ti)))
@@ -89,12 +89,15 @@ def test_config2_headline_launch_cornell_1080p_512spp_split8(H, L, orc_lib, devm
     """the launch bench.py times: 1920x1080, 512 spp, sample_split 8 (lean counters, no per-pixel draw counts)
     == 8 reference calls of 64 spp"""
     d = scenes.cornell_box(1920, 1080, 512, bounces=8)
-    got = device_frame(L, d, split=8, calls=False)            # exactly bench.py's launch: library-default (automatic) traversal, split 8, lean counters
+    got = device_frame(L, d, split=8, calls=False, counters=False)      # exactly bench.py's timed launch: library defaults -- automatic traversal, no work counters -- and split 8
     assert got["tree_mode"] == 2 and got["traversal"] == "reference tree + leaf-box cull"      # what BENCH's config.traversal names
     assert (got["samples"] == 512).all() and np.isfinite(got["pixels"]).all()
-    s = got["stats"]
-    assert s["samples"] == 1920 * 1080 * 512 and s["pixels"] == 1920 * 1080 and s["rand_calls"] == 4 * s["hits"]
-    counted = device_frame(L, d, split=8, calls=True)         # the fully counting variant: same frame + per-pixel stream-B draws
+    assert got["stats"]["samples"] == 1920 * 1080 * 512 and got["stats"]["pixels"] == 1920 * 1080 and got["stats"]["rays"] == 0      # (host-kept totals; the device counters are off)
+    lean = device_frame(L, d, split=8, calls=False)           # bench.py's extra counting launch: the same frame, counters on
+    assert H.same_bits(lean["acc"], got["acc"]) and H.same_bits(lean["pixels"], got["pixels"])
+    s = lean["stats"]
+    assert s["samples"] == 1920 * 1080 * 512 and s["pixels"] == 1920 * 1080 and s["rand_calls"] == 4 * s["hits"] and s["rays"] > s["samples"]
+    counted = device_frame(L, d, split=8, calls=True)         # ... and with per-pixel stream-B draw counts
     assert H.same_bits(counted["acc"], got["acc"]) and H.same_bits(counted["pixels"], got["pixels"])
     assert int(counted["rand_calls"].astype(np.uint64).sum()) == s["rand_calls"]
     got["rand_calls"] = counted["rand_calls"]
