@@ -3,7 +3,7 @@ cycles from the measured per-class issue rates (profiles/r02_measurements/valu_r
 2.4 GHz with 4 waves per SIMD). Usage: tools/kernel_resources.sh; python tools/isa_cost.py [mangled-name-substring]"""
 import re, sys, collections
 S = "/tmp/terra_isa/render_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
-name = sys.argv[1] if len(sys.argv) > 1 else "ILi0ELi1ELi1ELi1E"
+name = sys.argv[1] if len(sys.argv) > 1 else "ILi0ELi0ELi1ELi1E"
 FAST = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32", "v_accvgpr"}
 MED = {"v_and_b32": 3.3, "v_or_b32": 3.3, "v_xor_b32": 3.4, "v_add_u32": 3.5, "v_sub_u32": 3.5, "v_subrev_u32": 3.5, "v_lshrrev_b32": 2.9, "v_fma_f32": 3.9, "v_fmac_f32": 4.1, "v_not_b32": 3.3}
 TRANS = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_f64", "v_rsq_f64", "v_sqrt_f64"}
