@@ -43,7 +43,11 @@ TD void wave_flush_counters ( const Counters& c, unsigned long long* g ) {
 // per-thread words parked in LDS between uses (indexed [word][thread] like the stack): the radiance sum of the lane's
 // current job (touched once per path), the job's number and the lane's draw count when the job started (read at its end), and a row
 // that holds each wave's pool of claimed jobs (render_kernels.hip "jobs")
-#define TERRA_AUX_WORDS 6
+#define TERRA_AUX_WORDS 6        // rows every launch has (acc x 3, job, draw count, wave pools)
+#define TERRA_AUX_WORDS_LDS 9    // ... plus, on LDS-resident scenes (lds_mode 1), the path radiance Lo x 3 (TERRA_LO_IN_LDS)
+#ifndef TERRA_LO_IN_LDS          // the coupled loop of LDS-resident scenes keeps the current path's radiance (three words that change on few hits) in rows 6-8 instead of registers
+#define TERRA_LO_IN_LDS 1
+#endif
 #ifndef TERRA_CHECK_SHRINK
 #define TERRA_CHECK_SHRINK 0
 #endif
@@ -567,6 +571,17 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     // ray per iteration; a lane whose path ended starts its pixel's next sample in the same iteration, or its next job.
     bool alive = false;
     V3 ro = v3 ( 0, 0, 0 ), rd = v3 ( 0, 0, 1 );                     // origin / direction of the lane's next ray; the reciprocals are taken in ONE place for camera and continuation rays
+    // The path's radiance Lo: a term is added on the few hits that emit (or, Direct / MIS, are lit) and the sum is needed when the path ends -- in between it only
+    // occupies three registers of a kernel that has none to spare. LDS-resident scenes park it next to the job's sum. Adding a term of +-0 would leave every
+    // component as it is (Lo is never -0: it starts at +0 and x + (-x) = +0), so skipping such terms is exact.
+    constexpr bool LO_LDS = TERRA_LO_IN_LDS && MODE == 1;
+    float* lo_lds = acc_lds + 6 * 256;
+    auto lo_reset = [&] () { if ( LO_LDS ) { lo_lds[0] = 0.f; lo_lds[256] = 0.f; lo_lds[512] = 0.f; } else Lo = v3 ( 0, 0, 0 ); };
+    auto lo_add = [&] ( V3 t ) {
+        if ( LO_LDS ) { if ( t.x != 0.f || t.y != 0.f || t.z != 0.f ) { lo_lds[0] = lo_lds[0] + t.x; lo_lds[256] = lo_lds[256] + t.y; lo_lds[512] = lo_lds[512] + t.z; } }
+        else Lo = Lo + t;
+    };
+    auto lo_deposit = [&] () { if ( LO_LDS ) deposit ( acc_lds, v3 ( lo_lds[0], lo_lds[256], lo_lds[512] ) ); else deposit ( acc_lds, Lo ); };
     while ( true ) {
         const bool any_alive = __any ( alive );
         if ( !alive ) {
@@ -578,7 +593,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                 ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
                 if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) sp = sampler_pair_draw ( p.sampler_mode, p.sampler_strata, ( uint64_t ) jb.base + jb.s, rs.a );
-                Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++jb.s;
+                lo_reset(); throughput = v3 ( 1, 1, 1 ); bounce = 0; alive = true; ++jb.s;
             }
         }
         if ( alive ) {
@@ -592,16 +607,16 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
             if ( h.hit ) {
                 PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
                 V3 wo = neg ( ray.d ), wi;
-                Lo = Lo + integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c );
+                lo_add ( integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c ) );
                 if ( !pre_draw ) pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );
                 if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) path_apply_sampler ( pd, sp, bounce );
                 end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                 if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }      // surface_ray ( sf, h.point, wi, 1.f ): its make_ray is the one at the top of this block
             } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
                 throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
-                Lo = Lo + throughput;
+                lo_add ( throughput );
             }
-            if ( end ) { deposit ( acc_lds, Lo ); alive = false; }
+            if ( end ) { lo_deposit(); alive = false; }
         }
     }
     }
@@ -633,7 +648,7 @@ static size_t scene_extra_lds_bytes ( uint32_t n_objects, uint32_t n_lights, uin
     return ( ( ( size_t ) n_objects * sizeof ( DevMaterial ) + 15 ) & ~size_t ( 15 ) ) + ( size_t ) n_lights * sizeof ( DevLight ) + ( ( ( size_t ) n_tris * 4 + 15 ) & ~size_t ( 15 ) );
 }
 size_t terra_lds_bytes ( const DevRenderParams& p ) {
-    return ( size_t ) ( p.stack_depth + p.leaf_cap + TERRA_AUX_WORDS ) * 1024 + ( size_t ) p.lds_nodes * ( p.lds_mode == 2 ? 64 : TERRA_LDS_NODE_BYTES ) + ( size_t ) p.lds_tris * ( 48 + 64 )
+    return ( size_t ) ( p.stack_depth + p.leaf_cap + ( p.lds_mode == 1 ? TERRA_AUX_WORDS_LDS : TERRA_AUX_WORDS ) ) * 1024 + ( size_t ) p.lds_nodes * ( p.lds_mode == 2 ? 64 : TERRA_LDS_NODE_BYTES ) + ( size_t ) p.lds_tris * ( 48 + 64 )
            + ( p.lds_mode == 1 ? scene_extra_lds_bytes ( p.scene.n_objects, p.scene.n_lights, p.scene.n_tris ) : 0 );
 }
 // fast tree (MODE 2): nodes of its breadth-first prefix staged per block. The kernel is latency bound (a ray's node fetches are a
@@ -672,7 +687,7 @@ void terra_plan_fast_tree ( DevRenderParams& p ) {
 // leaf-list entries an LDS-resident plan can afford (0 = the scene does not fit)
 static uint32_t resident_leaf_cap ( uint32_t n_nodes, uint32_t n_tris, int max_stack, uint32_t n_objects, uint32_t n_lights ) {
     const uint32_t depth = max_stack < 1 ? 1u : ( uint32_t ) max_stack;
-    const size_t fixed = ( size_t ) ( depth + TERRA_AUX_WORDS ) * 1024 + ( size_t ) n_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) n_tris * 112 + scene_extra_lds_bytes ( n_objects, n_lights, n_tris );
+    const size_t fixed = ( size_t ) ( depth + TERRA_AUX_WORDS_LDS ) * 1024 + ( size_t ) n_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) n_tris * 112 + scene_extra_lds_bytes ( n_objects, n_lights, n_tris );
     if ( fixed + ( size_t ) TERRA_LEAF_CAP_RESIDENT_MIN * 1024 > ( size_t ) TERRA_LDS_BUDGET ) return 0;
     const uint32_t cap = ( uint32_t ) ( ( ( size_t ) TERRA_LDS_BUDGET - fixed ) / 1024 );
     return cap > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : cap;

@@ -246,7 +246,7 @@ struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 #define TERRA_REACH_MAX_COORD 1e6f       // beyond it (c - o) x 2^100 (the fast tree's clamped slab test) approaches the binary32 range: replica
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
 #define TERRA_FAST_STACK_LDS_LIMIT ( 64 * 1024 )   // dynamic LDS a block may ask for without an opt-in; a fast-tree launch needs (depth + aux words) KB + its staged node prefix
-#define TERRA_FAST_STACK_AUX_KB 5                   // render_kernels.hip TERRA_AUX_WORDS
+#define TERRA_FAST_STACK_AUX_KB 6                   // render_kernels.hip TERRA_AUX_WORDS
 struct Scene {
     TerraSceneOptions opts, new_opts;
     TerraObject* objects = nullptr; size_t objects_pop = 0, objects_cap = 0;
