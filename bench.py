@@ -505,7 +505,13 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
 def result_block(d, name, tree, split, steps, warmup, world, m, spp_override, integrator_name):
     frame_samples = d.width * d.height * d.spp
     st = m["per_launch"] or {}
-    trav = ("fast tree + reachability replay" if "reachability" in m["traversal"]["note"] else "fast tree") if m["traversal"]["fast_tree"] else ("reference tree + leaf-box cull" if m["traversal"]["leaf_cull"] else "reference tree, replica traversal")
+    # the traversal the render calls actually ran (TerraAmdTraversalInfo::last_call: the commit-time decision can be overridden per call by the camera position)
+    from terra_amd import runtime
+    lc = m["traversal"].get("last_call")
+    if lc in runtime.CALL_TRAVERSAL and lc:
+        trav = runtime.CALL_TRAVERSAL[lc]
+    else:
+        trav = ("fast tree + reachability replay" if "reachability" in m["traversal"]["note"] else "fast tree") if m["traversal"]["fast_tree"] else ("reference tree + leaf-box cull" if m["traversal"]["leaf_cull"] else "reference tree, replica traversal")
     out = {"value": round(frame_samples * steps / m["elapsed"] / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(m["elapsed"] / steps * 1e3, 3),
            "config": {"workload": name, "scene": d.name, "width": d.width, "height": d.height, "spp": d.spp, "bounces": d.bounces, "integrator": integrator_name,

@@ -203,6 +203,30 @@ def test_automatic_traversal_decision(H, L):
     assert _decision(L, d)[1:3] == (0, 0)
 
 
+def test_fast_tree_too_deep_for_the_lds_stack_falls_back(H, L):
+    """The fast-tree launch plans 1 KB of LDS per stack entry and block (terra_plan_fast_tree); a tree whose depth would exceed what a block may ask for must not
+    be chosen at commit -- the scene keeps the reference tree, which always fits -- instead of failing every render. Clustered geometry does it: 5,000 triangles
+    whose extents nest like onion shells force a chain-like tree on any builder."""
+    n = 5000
+    k = np.arange(n, dtype=np.float64)
+    r = (1e-3 * 1.002 ** k).astype(np.float32)                      # nested shells from 1e-3 to ~22 units: every split separates one shell from the rest
+    tris = np.zeros((n, 3, 3), np.float32)
+    tris[:, 0, 0] = r; tris[:, 1, 1] = r; tris[:, 2, 2] = r          # triangle k spans (r,0,0) (0,r,0) (0,0,r): box [0, r]^3, all sharing the origin corner
+    nrm = np.tile(np.array([0.577, 0.577, 0.577], np.float32), (n, 3, 1))
+    od = scenes.ObjectDesc(triangles=tris, normals=nrm, texcoords=np.zeros((n, 3, 2), np.float32), material=scenes.Material(kind="diffuse", albedo=(0.5, 0.5, 0.5)))
+    d = scenes.SceneDesc(objects=[od], width=16, height=16, spp=1)
+    for mode in (2, 1):
+        L.clear_error()
+        scene = scenes.build_scene(L, d, tree_mode=mode)
+        ti = runtime.TraversalInfo(); assert L.traversal_info(scene, C.byref(ti)) == 0
+        note = ti.note.decode()
+        if ti.fast_tree:                                                 # shallow enough after all: then it must fit the limit the commit checks
+            assert "stack" not in note
+        else:
+            assert "stack" in note and "reference tree" in note, note
+        L.scene_destroy(scene); L.clear_error()
+
+
 def test_first_error_is_process_wide_and_sticky(H, L):
     """a worker thread's failure is visible to the thread that polls; the first one is kept until cleared"""
     import threading
