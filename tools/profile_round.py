@@ -11,6 +11,7 @@ HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 128
 """
 import argparse
 import collections
+import re
 import csv
 import glob
 import json
@@ -64,6 +65,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--round", default="r03")
+    ap.add_argument("--reaggregate", action="store_true", help="no runs: rebuild the JSON and the summary from the per-pass CSVs (and bench lines) an earlier run left under --out")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     out = Path(a.out or str(ROOT / "gpurun_out" / f"{a.round}_prof")); out.mkdir(parents=True, exist_ok=True)
@@ -79,26 +81,41 @@ def main():
         args = ["bench.py", "--workload", wl, "--tree", tree, "--sample-split", str(split), "--no-cpu-baseline", "--no-workloads", "--no-host-api"] + extra
         d = out / tag; d.mkdir(exist_ok=True)
         print("==", key, flush=True)
-        rc, so = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d / "trace"), "--", "python3"] + args, d / "trace.err")
-        line = [ln for ln in so.splitlines() if ln.startswith("{")]
-        if rc != 0 or not line:
-            print("  trace run failed", rc, open(d / "trace.err").read()[-500:]); continue
-        bl = json.loads(line[-1])
+        if a.reaggregate:
+            if (d / "bench_line.json").exists():
+                bl = json.loads((d / "bench_line.json").read_text())
+            elif key in result:          # an earlier version did not keep the line: rebuild the fields the summary needs from the JSON record
+                o = result[key]
+                bl = {"roofline": {"kernel_ms": o["kernel_ms"], "algorithmic_bytes_per_launch": bench.algorithmic_bytes(o["counters_per_launch"])}, "ms_per_step": o["ms_per_step"], "value": o["value"],
+                      "counters_per_launch": o["counters_per_launch"], "config": {"traversal": o["traversal"]}}
+            else:
+                continue
+        else:
+            rc, so = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d / "trace"), "--", "python3"] + args, d / "trace.err")
+            line = [ln for ln in so.splitlines() if ln.startswith("{")]
+            if rc != 0 or not line:
+                print("  trace run failed", rc, open(d / "trace.err").read()[-500:]); continue
+            bl = json.loads(line[-1])
+            (d / "bench_line.json").write_text(json.dumps(bl))
         rec = {"source_digest": digest, "kernel_ms": bl["roofline"]["kernel_ms"], "ms_per_step": bl["ms_per_step"], "value": bl["value"], "counters_per_launch": bl["counters_per_launch"],
                "traversal": bl["config"]["traversal"]}
         stats_rows = []
         for fcsv in glob.glob(f"{d}/trace/**/*_kernel_stats.csv", recursive=True):
             rows = list(csv.reader(open(fcsv)))
-            stats_rows = [rows[0]] + [r for r in rows[1:] if "terra_" in r[0]]
+            stats_rows = [rows[0]] + [r for r in rows[1:] if "terra_" in r[0] and "sincos24" not in r[0]]
         allc = {}; meta_r = {}; per_kernel = {}
         for pname, ctrs in PASSES.items():
-            rc, so = run(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", str(d / pname), "--", "python3"] + args, d / f"{pname}.err")
-            if rc != 0:
-                print("  pass", pname, "failed", rc, open(d / f"{pname}.err").read()[-300:]); continue
+            if not a.reaggregate:
+                rc, so = run(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", str(d / pname), "--", "python3"] + args, d / f"{pname}.err")
+                if rc != 0:
+                    print("  pass", pname, "failed", rc, open(d / f"{pname}.err").read()[-300:]); continue
             c, m = counters(d / pname)
+            # bench.py's timed launches run WITHOUT work counters (template argument COUNT = 0); its one extra counting launch is another instance
+            # of the kernel (COUNT = 2) and must not be mixed in: the record is the timed kernel's
+            timed = [k for k in c if re.search(r"terra_render_kernel<\d+, 0,", k)] or [k for k in c if "terra_render_kernel" in k]
             for k, v in c.items():
                 per_kernel.setdefault(k, {}).update(v)
-                if "terra_render_kernel" in k:
+                if k in timed[:1]:
                     allc.update(v); meta_r = m[k]; rec["kernel_name"] = k.split("(")[0].replace("void ", "")
             print("  pass", pname, "ok", flush=True)
         g = allc.get
@@ -121,7 +138,7 @@ def main():
         md.append("`rocprofv3 --kernel-trace --stats -- python3 " + " ".join(args) + "` (+ separate `--pmc` passes: " + ", ".join(PASSES) + ")\n")
         md.append("```\n" + "\n".join(",".join(r) for r in stats_rows) + "\n```")
         md.append(f"bench.py's own HIP-event timing in the traced run: kernel_ms = {bl['roofline']['kernel_ms']}, ms_per_step = {bl['ms_per_step']}, {bl['value']} Msamples/s; traversal: {bl['config']['traversal']}\n")
-        md.append("render kernel, per launch:\n```")
+        md.append(f"render kernel ({rec.get('kernel_name', '?')}: the timed launches, no work counters), per launch:\n```")
         for k in sorted(allc):
             md.append(f"{k:26s} {allc[k]:.6g}")
         md.append("```")
