@@ -575,9 +575,10 @@ def host_api(c, d, tree, split, steps):
 
 EXTRA_WORKLOADS = [
     # (workload, tree, integrator, split, steps, warmup, prewarm rectangle, CPU seconds)
-    ("hall_1080p_256spp", "auto", "simple", 1, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
-    ("hall_1080p_256spp", "reference", "simple", 1, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (6 s per step)
-    ("hall_x100_1080p_64spp", "auto", "simple", 1, 2, 1, None, 6.0),                   # the hall outside the coordinate range: fast tree + reachability replay
+    # (sample split: with the job queue a launch wants >= ~20 jobs per resident lane, or its last jobs ramp down alone: hall 256 spp split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms)
+    ("hall_1080p_256spp", "auto", "simple", 8, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
+    ("hall_1080p_256spp", "reference", "simple", 8, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (5 s per step)
+    ("hall_x100_1080p_64spp", "auto", "simple", 4, 2, 1, None, 6.0),                   # the hall outside the coordinate range: fast tree + reachability replay
     ("spheres_1080p_1024spp", "auto", "simple", 8, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
     ("cornell_1080p_512spp_direct", "auto", "direct", 8, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
 ]

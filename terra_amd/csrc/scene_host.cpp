@@ -1077,10 +1077,11 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
     const uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return 0;
     if ( split == 0 ) {
-        // automatic: enough blocks to fill the GPU about twice (256 CUs x 5 resident blocks), chunks of at least 16 samples.
-        // Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
+        // automatic: about 48 jobs per lane the GPU holds at once (256 CUs x 5 blocks x 256 lanes), chunks of at least 16 samples. A launch whose lanes get only
+        // a handful of jobs each ends with its last jobs ramping down alone (hall 1080p 256 spp: split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms); a small tile wants
+        // the split to fill the GPU at all. Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
         split = 1;
-        while ( split < 16 && blocks * split < 2560 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
+        while ( split < 16 && ( uint64_t ) blocks * split < 61440 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
     }
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
     if ( split < 1 ) split = 1;

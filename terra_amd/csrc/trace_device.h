@@ -583,7 +583,9 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
         if ( TERRA_REACH_SELFCHECK || ( mask & 1u ) ) {
             if ( !slab<false> ( v3 ( a.x, a.y, a.z ), v3 ( b.x, b.y, b.z ), ray ) ) {
                 if ( !TERRA_REACH_SELFCHECK ) return false;
-                if ( mask & 1u ) ok = false; else if ( T.faults ) atomicAdd ( T.faults, 1ull );      // a cleared level failed: the mask is wrong
+                // a cleared level that fails while every tested level below it passed: the mask is wrong. (After a tested level has failed, the levels above may
+                // fail too -- "contains the level below" only promises that a pass propagates upwards -- and mean nothing.)
+                if ( mask & 1u ) ok = false; else if ( ok && T.faults ) atomicAdd ( T.faults, 1ull );
             }
         }
         q = __float_as_uint ( a.w );

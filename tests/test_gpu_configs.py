@@ -126,9 +126,10 @@ _hall_want = {}
 
 @pytest.mark.parametrize("tree_mode", [None, 0, 1])
 def test_config3_hall_1080p_256spp(H, L, orc_lib, devmath_mode, tree_mode):
-    """None = the library default (automatic), the launch bench.py's `hall_1080p_256spp` workload times"""
+    """None = the library default (automatic) with bench.py's sample split of 8: the launch its `hall_1080p_256spp` workload times
+    (= the framebuffer of 8 successive calls of 32 spp)"""
     d = scenes.sponza_hall(1920, 1080, 256, bounces=8)
-    got = device_frame(L, d, split=1, tree_mode=tree_mode)
+    got = device_frame(L, d, split=8, tree_mode=tree_mode)
     assert got["traversal"] == {None: "fast tree", 0: "reference tree, replica traversal", 1: "fast tree"}[tree_mode]
     assert got["tree_mode"] == (2 if tree_mode is None else tree_mode)
     assert 90_000 <= got["triangles"] <= 110_000
@@ -136,7 +137,7 @@ def test_config3_hall_1080p_256spp(H, L, orc_lib, devmath_mode, tree_mode):
     assert got["stats"]["samples"] == 1920 * 1080 * 256 and got["stats"]["rand_calls"] == 4 * got["stats"]["hits"]
     rect = (1000, 600, 48, 32)
     if "w" not in _hall_want:                                   # one oracle run serves all tree modes (0.4 M samples of 474 nodes/ray each)
-        _hall_want["w"] = H.Unit("orc").render_pixels(d, rect=rect, threads=THREADS)
+        _hall_want["w"] = H.Unit("orc").render_pixels(scenes.sponza_hall(1920, 1080, 32, bounces=8), passes=8, rect=rect, threads=THREADS, sum_calls=True)
     assert_crop_equals_oracle(H, got, _hall_want["w"], rect)
 
 
@@ -146,12 +147,14 @@ def test_hall_x100_1080p_64spp_reachability_mode(H, L, orc_lib, devmath_mode):
     import bench
     d = bench.workload("hall_x100_1080p_64spp")
     assert (d.width, d.height, d.spp) == (1920, 1080, 64)
-    got = device_frame(L, d, split=1)
+    assert [w for w in bench.EXTRA_WORKLOADS if w[0] == "hall_x100_1080p_64spp"][0][3] == 4 and [w for w in bench.EXTRA_WORKLOADS if w[0] == "hall_1080p_256spp"][0][3] == 8
+    got = device_frame(L, d, split=4)                           # bench.py's launch: sample split 4 = the framebuffer of 4 successive calls of 16 spp
     assert got["tree_mode"] == 2 and got["traversal"] == "fast tree + reachability replay"
     assert (got["samples"] == 64).all() and np.isfinite(got["pixels"]).all()
     assert got["stats"]["samples"] == 1920 * 1080 * 64 and got["stats"]["rand_calls"] == 4 * got["stats"]["hits"]
+    d16 = bench.workload("hall_x100_1080p_64spp", 16)
     for rect in ((1000, 600, 48, 32), (300, 820, 32, 16)):
-        want = H.Unit("orc").render_pixels(d, rect=rect, threads=THREADS)
+        want = H.Unit("orc").render_pixels(d16, passes=4, rect=rect, threads=THREADS, sum_calls=True)
         assert_crop_equals_oracle(H, got, want, rect)
 
 

@@ -18,13 +18,15 @@ if __name__ == "__main__":
     import torch  # before the library: libterra_amd.so must bind to the HIP runtime torch loaded
     ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=float, default=100.0); ap.add_argument("--spp", type=int, default=8); ap.add_argument("--integrator", type=int, default=0)
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--shrink", type=float, default=0.0, help="terra_amd_debug_shrink_reference_boxes: the device's copy of the reference boxes shrunk by this much (gives the reachability replay work)")
+    ap.add_argument("--builder", type=int, default=None, help="terra_amd_set_tree_builder: 0 host binned SAH, 1 device LBVH")
     a = ap.parse_args()
     from terra_amd import runtime
     L = runtime.load()
     outs = {}
     for mode in (2, 0):
         d = scaled(scenes.sponza_hall(a.width, a.height, a.spp, bounces=8, integrator=a.integrator), a.scale)
-        L.clear_error(); s = scenes.build_scene(L, d, tree_mode=mode)
+        L.clear_error(); s = scenes.build_scene(L, d, tree_mode=mode, debug_shrink=a.shrink or None, tree_builder=a.builder)
         ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(s, C.byref(ti)))
         fb = runtime.DeviceFramebuffer(d.width, d.height); cam = scenes.camera_of(d)
         runtime.render_device(L, cam, s, fb); torch.cuda.synchronize(); fb.clear()
