@@ -299,9 +299,8 @@ TD void deposit ( float* acc_lds, V3 Lo ) { acc_lds[0] = acc_lds[0] + Lo.x; acc_
 // samples already in the pixel + chunk * chunk_spp) and summed from zero into partials[] (DevRenderParams::split; split == 1: the
 // call's one sum per pixel). Jobs are numbered like the threads of a plain launch would be -- job = virtual block * 256 + virtual
 // thread, virtual block = (16x16 pixel block of the shard) * split + chunk -- and the grid is PERSISTENT: at most as many blocks
-// as the GPU holds at once (terra_launch_render). A wave starts with the 64 jobs of its own index and, when those are handed out,
-// claims the next unclaimed batch of 64 from a queue word in HBM (one atomic per 64 jobs); its lanes take jobs from the wave's
-// pool (two words of LDS) whenever their own is finished. What a job computes does not depend on which lane runs it, so the frame
+// as the GPU holds at once (terra_launch_render). A wave claims the next unclaimed batch of 64 jobs from a queue word in HBM (one atomic per
+// 64 jobs) whenever its pool (two words of LDS) is empty; its lanes take jobs from the pool whenever their own is finished. What a job computes does not depend on which lane runs it, so the frame
 // is the plain launch's bit for bit; what changes is that a wave's 64 lanes no longer wait for the slowest of 64 fixed pixels
 // (paths have random lengths: with 64-sample chunks 13 % of the lane time of the Cornell frame was spent in that ramp-down,
 // profiles/r02_measurements/phase_cornell.log) and that the launch has no tail of half-empty rounds.
@@ -344,10 +343,14 @@ TD bool job_pixel ( const DevRenderParams& p, uint32_t job, uint32_t& px, uint32
 TD uint32_t* job_pool_of_wave ( float* aux_of_thread ) { return reinterpret_cast<uint32_t*> ( aux_of_thread - threadIdx.x ) + 1280 + ( threadIdx.x & ~63u ); }
 TD void job_init_lane ( const DevRenderParams& p, float* aux ) {
     reinterpret_cast<uint32_t*> ( aux ) [768] = TERRA_JOB_NONE;
-    if ( ( threadIdx.x & 63u ) == 0 ) {       // the wave's first pool: the jobs of its own index
+    if ( ( threadIdx.x & 63u ) == 0 ) {       // the wave's first pool
         uint32_t* pool = job_pool_of_wave ( aux );
-        const uint32_t total = p.job_blocks * 256u, first = blockIdx.x * 256u + threadIdx.x;
-        pool[0] = first < total ? first : total; pool[1] = first + TERRA_JOB_BATCH < total ? first + TERRA_JOB_BATCH : total;
+        if ( p.job_queue ) { pool[0] = 0; pool[1] = 0; }      // empty: the first ask claims a batch from the queue like every later one. (No job is RESERVED for a block by its index:
+                                                              // a block that the GPU only makes resident late -- when others have drained the queue -- finds nothing and leaves.)
+        else {                                                // plain launch (no queue): the 64 jobs of the wave's own index
+            const uint32_t total = p.job_blocks * 256u, first = blockIdx.x * 256u + threadIdx.x;
+            pool[0] = first < total ? first : total; pool[1] = first + TERRA_JOB_BATCH < total ? first + TERRA_JOB_BATCH : total;
+        }
     }
 }
 // Job boundary, for whichever lanes of the wave call it together: store the finished job's sum, take the next job from the wave's pool (claiming a new batch from
@@ -376,7 +379,7 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
                                                                  //  no queue: a plain launch, every lane has the one job of its own index)
         uint32_t base = 0;
         if ( ahead == 0 ) base = atomicAdd ( p.job_queue, TERRA_JOB_BATCH );
-        base = gridDim.x * 256u + ( uint32_t ) __builtin_amdgcn_readfirstlane ( ( int ) base );
+        base = ( uint32_t ) __builtin_amdgcn_readfirstlane ( ( int ) base );
         next = base < total ? base : total; end = base + TERRA_JOB_BATCH < total ? base + TERRA_JOB_BATCH : total;
         const uint32_t take2 = n - take < end - next ? n - take : end - next;
         if ( !got ) { job = next + ( ahead - take ); got = ahead - take < take2; }
