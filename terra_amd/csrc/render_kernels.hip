@@ -577,7 +577,10 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     // The path's radiance Lo: a term is added on the few hits that emit (or, Direct / MIS, are lit) and the sum is needed when the path ends -- in between it only
     // occupies three registers of a kernel that has none to spare. LDS-resident scenes park it next to the job's sum. Adding a term of +-0 would leave every
     // component as it is (Lo is never -0: it starts at +0 and x + (-x) = +0), so skipping such terms is exact.
-    constexpr bool LO_LDS = TERRA_LO_IN_LDS && MODE == 1;
+#ifndef TERRA_LO_IN_LDS_LIGHT     // ... also for Direct / MIS, whose Lo changes on most hits (A/B)
+#define TERRA_LO_IN_LDS_LIGHT 1
+#endif
+    constexpr bool LO_LDS = TERRA_LO_IN_LDS && MODE == 1 && ( TERRA_LO_IN_LDS_LIGHT || !TERRA_IS_LIGHT ( INTEGRATOR ) );
     float* lo_lds = acc_lds + 6 * 256;
     auto lo_reset = [&] () { if ( LO_LDS ) { lo_lds[0] = 0.f; lo_lds[256] = 0.f; lo_lds[512] = 0.f; } else Lo = v3 ( 0, 0, 0 ); };
     auto lo_add = [&] ( V3 t ) {
