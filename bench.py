@@ -18,7 +18,7 @@ scene replica, and ONE gather (RCCL over xGMI; terra_amd.runtime.gather_frame, t
 packed tiles to rank 0, which unpacks them into the full frame. Pack, gather and unpack run on a second stream: the next
 step's render (disjoint tiles) starts as soon as the pack has read the rank's own tiles. Total work is fixed as N grows:
 "scaling": "strong". value = frame samples * K / max-over-ranks wall time. Every rank count renders with the same sample split
-(terra_amd_set_sample_split, default 8 lanes per pixel: the frame of 8 successive 64-spp calls), so the image does not
+(terra_amd_set_sample_split, default 16 lanes per pixel: the frame of 16 successive 32-spp calls), so the image does not
 depend on N and a 1/8 share of the frame still fills a GPU.
 
 Also on the JSON line (rank 0):
@@ -56,6 +56,10 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (MI355X_MICROARCH.md "Execution model")
 TILE = 64
+# Sample split of the timed launches (terra_amd_set_sample_split): the frame equals that of this many successive calls of spp/split samples. With the job queue a
+# launch wants many jobs per resident lane -- at N = 8 a rank renders an eighth of the frame -- and 16 measures best at N = 1 too (Cornell 512 spp: split 8 / 16 / 32 / 64
+# -> 58.6 / 57.2 / 56.7 / 60.6 ms; slowest 1/8 share 9.04 / 8.44 / 8.34 / 8.25 ms; profiles/r03_measurements/shard_balance.log)
+DEFAULT_SPLIT = 16
 TREE_MODES = {"auto": 2, "reference": 0, "fast": 1}
 INTEGRATORS = {"simple": 0, "direct": 1, "mis": 2}
 
@@ -73,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other configurations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
     ap.add_argument("--tree", default="auto", choices=list(TREE_MODES), help="terra_amd_set_tree_mode: auto (2, the library default: leaf-box cull / fast tree when the scene passes the numeric containment check), reference (0: the reference's tree, every traversal decision reproduced), fast (1)")
-    ap.add_argument("--sample-split", type=int, default=8, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
+    ap.add_argument("--sample-split", type=int, default=DEFAULT_SPLIT, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
     ap.add_argument("--check", action="store_true", help="after timing: one low-spp sharded+gathered pass into a fresh frame must equal an unsharded pass bit for bit (rank 0); on by default when N > 1")
     ap.add_argument("--no-check", action="store_true", help="N > 1: skip that extra pass")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-started N-rank child may run before it is killed (a hung rendezvous must not hang the parent)")
@@ -576,11 +580,11 @@ def host_api(c, d, tree, split, steps):
 EXTRA_WORKLOADS = [
     # (workload, tree, integrator, split, steps, warmup, prewarm rectangle, CPU seconds)
     # (sample split: with the job queue a launch wants >= ~20 jobs per resident lane, or its last jobs ramp down alone: hall 256 spp split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms)
-    ("hall_1080p_256spp", "auto", "simple", 8, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
-    ("hall_1080p_256spp", "reference", "simple", 8, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (5 s per step)
+    ("hall_1080p_256spp", "auto", "simple", DEFAULT_SPLIT, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
+    ("hall_1080p_256spp", "reference", "simple", DEFAULT_SPLIT, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (5 s per step)
     ("hall_x100_1080p_64spp", "auto", "simple", 4, 2, 1, None, 6.0),                   # the hall outside the coordinate range: fast tree + reachability replay
-    ("spheres_1080p_1024spp", "auto", "simple", 8, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
-    ("cornell_1080p_512spp_direct", "auto", "direct", 8, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
+    ("spheres_1080p_1024spp", "auto", "simple", DEFAULT_SPLIT, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
+    ("cornell_1080p_512spp_direct", "auto", "direct", DEFAULT_SPLIT, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
 ]
 
 
@@ -620,7 +624,7 @@ def main():
             out["host_api"] = host_api(c, d, args.tree, args.sample_split, max(1, min(args.steps, 3)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
-        headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == 8
+        headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == DEFAULT_SPLIT
         if world == 1 and not c.dist_on and headline and not args.no_workloads:
             extra = []; cpu_cache = {}
             for name, tree, integ, split, steps, warmup, prewarm, cpu_s in EXTRA_WORKLOADS:

@@ -109,7 +109,7 @@ int  terra_amd_get_tree_builder ( HTerraScene scene );
    tree inside the coordinate range) are not taken and terra_amd_traversal_info() says so. */
 int  terra_amd_debug_shrink_reference_boxes ( HTerraScene scene, float amount );
 
-/* Sample split: how many lanes share one pixel. With split = S (1, 2, 4, 8 or 16; default 1) a render call of
+/* Sample split: how many lanes share one pixel. With split = S (a power of two up to 64; default 1) a render call of
    spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random
    streams keyed (pixel, samples already in the pixel + j * spp/S), and the chunk sums are added to the
    pixel in chunk order: bit for bit the framebuffer that S successive calls of spp/S samples produce

@@ -350,7 +350,7 @@ extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* 
     return 0;
 }
 extern "C" int terra_amd_set_sample_split ( HTerraScene h, int split ) {
-    if ( split != 0 && split != 1 && split != 2 && split != 4 && split != 8 && split != 16 ) return fail ( kTerraAmdErrBadArgument, "sample split %d: must be 0 (automatic), 1, 2, 4, 8 or 16", split );
+    if ( split < 0 || split > 64 || ( split & ( split - 1 ) ) != 0 ) return fail ( kTerraAmdErrBadArgument, "sample split %d: must be 0 (automatic) or a power of two up to 64", split );
     S ( h )->sample_split = ( uint32_t ) split;
     return 0;
 }

@@ -90,6 +90,6 @@ def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
         assert r["pmc_record"] == key and 0 < r["frac"] <= 1 and r["bound"] in ("valu", "l2_fabric")
         assert abs(r["frac"] - max(valu, fabric)) < 1e-3 and (r["bound"] == "valu") == (valu >= fabric or abs(valu - fabric) < 1e-3)
         assert 0 < r["lane_util"] <= 1 and r["algorithmic_gbs"] > 0
-    hk = "cornell_1080p_512spp|tree=auto|integrator=simple|split=8"
+    hk = bench.pmc_key("cornell_1080p_512spp", "auto", "simple", bench.DEFAULT_SPLIT, 0)          # the headline launch's record
     head = bench.roofline(hk, pmc[hk]["counters_per_launch"], pmc[hk]["kernel_ms"], True, 1)
     assert head["bound"] == "valu" and 0.6 < head["frac"] < 0.8 and head["pmc_file"] == "profiles/" + f.name

@@ -25,7 +25,10 @@ from terra_amd import api, runtime, scenes
 
 pytestmark = pytest.mark.gpu
 
+import bench  # noqa: E402  (nothing GPU-related at module level)
+
 TILE = 64       # bench.py's tile size
+SPLIT = bench.DEFAULT_SPLIT     # the sample split of bench.py's timed launches (16: the framebuffer of 16 successive calls of spp/16 samples)
 THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 
 
@@ -86,25 +89,24 @@ def device_frame(L, d, split=1, tree_mode=None, calls=True, shard=None, counters
 
 
 def test_config2_headline_launch_cornell_1080p_512spp_split8(H, L, orc_lib, devmath_mode):
-    """the launch bench.py times: 1920x1080, 512 spp, sample_split 8 (lean counters, no per-pixel draw counts)
-    == 8 reference calls of 64 spp"""
+    """the launch bench.py times: 1920x1080, 512 spp, its sample split (16: == 16 reference calls of 32 spp), library defaults"""
     d = scenes.cornell_box(1920, 1080, 512, bounces=8)
-    got = device_frame(L, d, split=8, calls=False, counters=False)      # exactly bench.py's timed launch: library defaults -- automatic traversal, no work counters -- and split 8
+    got = device_frame(L, d, split=SPLIT, calls=False, counters=False)      # exactly bench.py's timed launch: library defaults -- automatic traversal, no work counters -- and its sample split
     assert got["tree_mode"] == 2 and got["traversal"] == "reference tree + leaf-box cull"      # what BENCH's config.traversal names
     assert (got["samples"] == 512).all() and np.isfinite(got["pixels"]).all()
     assert got["stats"]["samples"] == 1920 * 1080 * 512 and got["stats"]["pixels"] == 1920 * 1080 and got["stats"]["rays"] == 0      # (host-kept totals; the device counters are off)
-    lean = device_frame(L, d, split=8, calls=False)           # bench.py's extra counting launch: the same frame, counters on
+    lean = device_frame(L, d, split=SPLIT, calls=False)           # bench.py's extra counting launch: the same frame, counters on
     assert H.same_bits(lean["acc"], got["acc"]) and H.same_bits(lean["pixels"], got["pixels"])
     s = lean["stats"]
     assert s["samples"] == 1920 * 1080 * 512 and s["pixels"] == 1920 * 1080 and s["rand_calls"] == 4 * s["hits"] and s["rays"] > s["samples"]
-    counted = device_frame(L, d, split=8, calls=True)         # ... and with per-pixel stream-B draw counts
+    counted = device_frame(L, d, split=SPLIT, calls=True)         # ... and with per-pixel stream-B draw counts
     assert H.same_bits(counted["acc"], got["acc"]) and H.same_bits(counted["pixels"], got["pixels"])
     assert int(counted["rand_calls"].astype(np.uint64).sum()) == s["rand_calls"]
     got["rand_calls"] = counted["rand_calls"]
     # two crops: inside the box (back wall), and the box's left border (background | red wall)
-    d64 = scenes.cornell_box(1920, 1080, 64, bounces=8)
+    dch = scenes.cornell_box(1920, 1080, 512 // SPLIT, bounces=8)
     for rect in ((936, 300, 48, 32), (400, 520, 48, 32)):
-        want = H.Unit("orc").render_pixels(d64, passes=8, rect=rect, threads=THREADS, sum_calls=True)
+        want = H.Unit("orc").render_pixels(dch, passes=SPLIT, rect=rect, threads=THREADS, sum_calls=True)
         assert (crop(want["samples"], rect) == 512).all()
         assert_crop_equals_oracle(H, got, want, rect)
     # the same frame without the split is a DIFFERENT (equally valid) frame: one call of 512 spp; its crop is the oracle's too
@@ -114,7 +116,7 @@ def test_config2_headline_launch_cornell_1080p_512spp_split8(H, L, orc_lib, devm
     assert_crop_equals_oracle(H, one, want1, rect)
     assert not H.same_bits(crop(one["acc"], rect), crop(got["acc"], rect))
     # the replica traversal (mode 0) renders the same split-8 frame, and is the mode whose work counters are the reference's
-    rep = device_frame(L, d, split=8, tree_mode=0, calls=False)
+    rep = device_frame(L, d, split=SPLIT, tree_mode=0, calls=False)
     assert rep["traversal"] == "reference tree, replica traversal"
     assert H.same_bits(rep["acc"], got["acc"]) and H.same_bits(rep["pixels"], got["pixels"])
     # (the cull launch's fused box test may decide a grazing box differently from the replica: node counts agree to parts per million; hits are the image's)
@@ -126,10 +128,10 @@ _hall_want = {}
 
 @pytest.mark.parametrize("tree_mode", [None, 0, 1])
 def test_config3_hall_1080p_256spp(H, L, orc_lib, devmath_mode, tree_mode):
-    """None = the library default (automatic) with bench.py's sample split of 8: the launch its `hall_1080p_256spp` workload times
-    (= the framebuffer of 8 successive calls of 32 spp)"""
+    """None = the library default (automatic) with bench.py's sample split: the launch its `hall_1080p_256spp` workload times
+    (= the framebuffer of 16 successive calls of 16 spp)"""
     d = scenes.sponza_hall(1920, 1080, 256, bounces=8)
-    got = device_frame(L, d, split=8, tree_mode=tree_mode)
+    got = device_frame(L, d, split=SPLIT, tree_mode=tree_mode)
     assert got["traversal"] == {None: "fast tree", 0: "reference tree, replica traversal", 1: "fast tree"}[tree_mode]
     assert got["tree_mode"] == (2 if tree_mode is None else tree_mode)
     assert 90_000 <= got["triangles"] <= 110_000
@@ -137,17 +139,16 @@ def test_config3_hall_1080p_256spp(H, L, orc_lib, devmath_mode, tree_mode):
     assert got["stats"]["samples"] == 1920 * 1080 * 256 and got["stats"]["rand_calls"] == 4 * got["stats"]["hits"]
     rect = (1000, 600, 48, 32)
     if "w" not in _hall_want:                                   # one oracle run serves all tree modes (0.4 M samples of 474 nodes/ray each)
-        _hall_want["w"] = H.Unit("orc").render_pixels(scenes.sponza_hall(1920, 1080, 32, bounces=8), passes=8, rect=rect, threads=THREADS, sum_calls=True)
+        _hall_want["w"] = H.Unit("orc").render_pixels(scenes.sponza_hall(1920, 1080, 256 // SPLIT, bounces=8), passes=SPLIT, rect=rect, threads=THREADS, sum_calls=True)
     assert_crop_equals_oracle(H, got, _hall_want["w"], rect)
 
 
 def test_hall_x100_1080p_64spp_reachability_mode(H, L, orc_lib, devmath_mode):
     """bench.py's `hall_x100_1080p_64spp` workload at its full size: every coordinate (scene and camera) x 100, i.e. outside the
     +-13-unit range of the containment proof -- the automatic mode keeps the fast tree and replays the reference's reachability"""
-    import bench
     d = bench.workload("hall_x100_1080p_64spp")
     assert (d.width, d.height, d.spp) == (1920, 1080, 64)
-    assert [w for w in bench.EXTRA_WORKLOADS if w[0] == "hall_x100_1080p_64spp"][0][3] == 4 and [w for w in bench.EXTRA_WORKLOADS if w[0] == "hall_1080p_256spp"][0][3] == 8
+    assert [w for w in bench.EXTRA_WORKLOADS if w[0] == "hall_x100_1080p_64spp"][0][3] == 4 and [w for w in bench.EXTRA_WORKLOADS if w[0] == "hall_1080p_256spp"][0][3] == SPLIT
     got = device_frame(L, d, split=4)                           # bench.py's launch: sample split 4 = the framebuffer of 4 successive calls of 16 spp
     assert got["tree_mode"] == 2 and got["traversal"] == "fast tree + reachability replay"
     assert (got["samples"] == 64).all() and np.isfinite(got["pixels"]).all()
@@ -161,13 +162,13 @@ def test_hall_x100_1080p_64spp_reachability_mode(H, L, orc_lib, devmath_mode):
 def test_config4_spheres_1080p_1024spp_unpinned(H, L, orc_lib, devmath_mode):
     """GGX + glass: device == oracle bit for bit, but the oracle's definition of these presets is this repo's (parity unpinned)"""
     d = scenes.cornell_spheres(1920, 1080, 1024, bounces=8)
-    got = device_frame(L, d, split=8)                          # library default, split 8: bench.py's `spheres_1080p_1024spp` launch
+    got = device_frame(L, d, split=SPLIT)                      # library default + bench.py's sample split: its `spheres_1080p_1024spp` launch
     assert got["tree_mode"] == 2 and got["traversal"] == "fast tree"
     assert (got["samples"] == 1024).all()
     assert got["stats"]["samples"] == 1920 * 1080 * 1024
-    d128 = scenes.cornell_spheres(1920, 1080, 128, bounces=8)
+    dch = scenes.cornell_spheres(1920, 1080, 1024 // SPLIT, bounces=8)
     for rect in ((1100, 700, 48, 32), (960, 760, 48, 32)):      # inside the glass sphere; metal sphere | gap | glass sphere silhouettes
-        want = H.Unit("orc").render_pixels(d128, passes=8, rect=rect, threads=THREADS, sum_calls=True)
+        want = H.Unit("orc").render_pixels(dch, passes=SPLIT, rect=rect, threads=THREADS, sum_calls=True)
         assert_crop_equals_oracle(H, got, want, rect)
     # the reference-tree kernel gives the same frame (thinner: 64 spp, the same streams as the first of the 8 passes would not
     # be comparable, so both trees are rendered at 64 spp)
@@ -213,16 +214,16 @@ def test_config5_hall_2160p_4096spp_eight_shards(H, L, orc_lib, devmath_mode):
     Full spp in the library-default automatic mode = the fast tree (34 G samples); the replica traversal at the same size is covered at 8 spp."""
     W, Ht, world = 3840, 2160, 8
     d = scenes.sponza_hall(W, Ht, 4096, bounces=8)
-    got = _sharded_frame(L, d, world, split=8)                 # library default (automatic): the fast tree
+    got = _sharded_frame(L, d, world, split=SPLIT)             # library default (automatic): the fast tree; bench.py's sample split
     assert got["traversal"] == "fast tree"
     assert (got["samples"] == 4096).all() and np.isfinite(got["pixels"]).all()
     tiles = -(-W // TILE) * -(-Ht // TILE)
     assert abs(got["rank0_pixels"] - W * Ht / world) <= 2 * TILE * TILE * (tiles % world + 1)      # the shard rule deals tiles evenly
-    d512 = scenes.sponza_hall(W, Ht, 512, bounces=8)
+    dch = scenes.sponza_hall(W, Ht, 4096 // SPLIT, bounces=8)
     # (the oracle walks the reference tree: 474 nodes per ray, so the crops are small)
     for rect in ((2000, 1200, 16, 8),          # inside tile (31, 18)
                  (2040, 1212, 16, 8)):         # straddles the tile borders x = 2048 and y = 1216: four tiles of four different ranks
-        want = H.Unit("orc").render_pixels(d512, passes=8, rect=rect, threads=THREADS, want_calls=False)
+        want = H.Unit("orc").render_pixels(dch, passes=SPLIT, rect=rect, threads=THREADS, want_calls=False)
         assert_crop_equals_oracle(H, got, want, rect, calls=False)
     # sharded == unsharded, every traversal mode, whole 4K frame (size-independent: 8 spp)
     for tree_mode in (None, 0, 1):

@@ -26,12 +26,12 @@ import bench  # noqa: E402  (imports nothing GPU-related at module level)
 
 CONFIGS = [
     # (workload, tree, integrator, split, extra bench args)
-    ("cornell_1080p_512spp", "auto", "simple", 8, ["--steps", "2", "--warmup", "1"]),
-    ("cornell_1080p_512spp", "reference", "simple", 8, ["--steps", "2", "--warmup", "1"]),
-    ("cornell_1080p_512spp_direct", "auto", "direct", 8, ["--steps", "2", "--warmup", "1"]),
-    ("hall_1080p_256spp", "auto", "simple", 8, ["--steps", "2", "--warmup", "1"]),
-    ("hall_1080p_256spp", "reference", "simple", 8, ["--steps", "1", "--warmup", "0"]),
-    ("spheres_1080p_1024spp", "auto", "simple", 8, ["--steps", "1", "--warmup", "1"]),
+    ("cornell_1080p_512spp", "auto", "simple", bench.DEFAULT_SPLIT, ["--steps", "2", "--warmup", "1"]),
+    ("cornell_1080p_512spp", "reference", "simple", bench.DEFAULT_SPLIT, ["--steps", "2", "--warmup", "1"]),
+    ("cornell_1080p_512spp_direct", "auto", "direct", bench.DEFAULT_SPLIT, ["--steps", "2", "--warmup", "1"]),
+    ("hall_1080p_256spp", "auto", "simple", bench.DEFAULT_SPLIT, ["--steps", "2", "--warmup", "1"]),
+    ("hall_1080p_256spp", "reference", "simple", bench.DEFAULT_SPLIT, ["--steps", "1", "--warmup", "0"]),
+    ("spheres_1080p_1024spp", "auto", "simple", bench.DEFAULT_SPLIT, ["--steps", "1", "--warmup", "1"]),
     ("hall_x100_1080p_64spp", "auto", "simple", 4, ["--steps", "2", "--warmup", "1"]),
 ]
 PASSES = {

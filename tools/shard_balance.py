@@ -12,7 +12,7 @@ ap.add_argument("--workload", default="cornell"); ap.add_argument("--split", typ
 a = ap.parse_args()
 lib = runtime.load()
 d = scenes.cornell_box(1920, 1080, a.spp, bounces=8) if a.workload == "cornell" else scenes.sponza_hall(1920, 1080, a.spp, bounces=8)
-scene = scenes.build_scene(lib, d); cam = scenes.camera_of(d)      # the default (automatic) traversal
+scene = scenes.build_scene(lib, d, counters=False); cam = scenes.camera_of(d)      # library defaults: automatic traversal, no work counters
 runtime.check(lib.set_sample_split(scene, a.split))
 fb = runtime.DeviceFramebuffer(d.width, d.height)
 def timed(fn):
