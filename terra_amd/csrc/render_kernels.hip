@@ -204,8 +204,8 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_WAVES_FAST_TREE      // fast-tree (MODE 2) kernels are latency bound: more resident waves pay for the extra scratch
 #define TERRA_WAVES_FAST_TREE 5     // (round 1, coupled loop: 4 -> 81.2 ms, 5 -> 71.0, 6 -> 67.2; with the decoupled loop, hall 64 spp: 5 -> 82.0 ms, 6 -> 83.6, 7 -> 89.0)
 #endif
-#ifndef TERRA_WAVES_FAST_TREE_LIGHT  // (hall, 16 spp, Direct / MIS: 4 -> 85.0 / 135.3 ms, 5 -> 79.3 / 122.2 ms, 6 -> 74.7 / 114.5 ms; ab_fl*.log)
-#define TERRA_WAVES_FAST_TREE_LIGHT 6
+#ifndef TERRA_WAVES_FAST_TREE_LIGHT  // (round 2, hall, 16 spp, Direct / MIS: 4 -> 85.0 / 135.3 ms, 5 -> 79.3 / 122.2 ms, 6 -> 74.7 / 114.5 ms; ab_fl*.log. Round 3, with the job queue and
+#define TERRA_WAVES_FAST_TREE_LIGHT 5 // without work counters, hall 64 spp: 5 -> 140.3 / 246.6 ms, 6 -> 163.5 / 267.5 ms; profiles/r03_measurements/ab_waves_light.log)
 #endif
 #ifndef TERRA_WAVES_GLOBAL_LIGHT     // reference tree read from global memory (MODE 0), Direct/MIS (sphere scene, Direct: 4 -> 864 ms, 5 -> 815 ms, 6 -> 841 ms; ab_gl*.log)
 #define TERRA_WAVES_GLOBAL_LIGHT 5
