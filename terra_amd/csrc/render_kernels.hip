@@ -152,6 +152,9 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_WAVES_LIGHT
 #define TERRA_WAVES_LIGHT 4
 #endif
+#ifndef TERRA_WAVES_DIRECT_PHONG // ... also the diffuse + Phong variant (A/B)
+#define TERRA_WAVES_DIRECT_PHONG 0
+#endif
 #ifndef TERRA_WAVES_DIRECT       // Direct on LDS-resident scenes, without work counters: 5 -> 117.7 ms, 4 -> 120.4 (Direct + MIS: 5 -> 191.9, 4 -> 178.9; profiles/r03_measurements/ab_waves_light.log)
 #define TERRA_WAVES_DIRECT 5
 #endif
@@ -218,7 +221,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #endif
 #define TERRA_IS_LIGHT(I) ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 )
 #define TERRA_WAVES_FOR(I, K, M) ( ( M ) == 2 ? ( ( K ) == 1 ? ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_LIGHT : TERRA_WAVES_FAST_TREE ) : ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_GENERIC_LIGHT : TERRA_WAVES_FAST_TREE_GENERIC ) ) \
-                                 : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : ( ( I ) == 1 && ( K ) == 1 ) ? TERRA_WAVES_DIRECT : TERRA_WAVES_LIGHT ) \
+                                 : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : ( ( I ) == 1 && ( ( K ) == 1 || ( TERRA_WAVES_DIRECT_PHONG && ( K ) == 3 ) ) ) ? TERRA_WAVES_DIRECT : TERRA_WAVES_LIGHT ) \
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
