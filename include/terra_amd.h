@@ -145,6 +145,20 @@ int  terra_amd_get_environment_lighting ( HTerraScene scene );
 int  terra_amd_set_sampler_integration ( HTerraScene scene, int on );
 int  terra_amd_get_sampler_integration ( HTerraScene scene );
 
+/* Environment importance sampling, off by default, PARITY UNPINNED ("TerraDistribution1D/2D for env-map importance sampling"). The reference
+   implements TerraDistribution2D (src/Terra.c:812-846) and nothing calls it. With on = 1, environment lighting on (above) and a lat-long environment TEXTURE of at
+   least three components, terra_scene_commit() tabulates the map as that distribution -- one value per texel, luminance (0.2126, 0.7152, 0.0722) x sin(theta of the
+   row's centre), initialised exactly as terra_distribution_2d_init does -- and the Direct and Direct+MIS integrators take ONE environment sample per shaded hit, after
+   their own light samples: two more draws of stream B choose a texel (the row from the first, the column from the second; terra_distribution_2d_sample's
+   arithmetic), the direction is the inverse of the lookup's mapping (src/Terra.c:468-477), the sample counts when it lies in the upper hemisphere of the shading
+   normal and its shadow ray leaves the scene, and it adds texel x BSDF x cosine / density (density = texel probability x texels / (2 terra_PI^2 sin theta)). A path
+   ray that leaves the scene after bounce 0 then no longer adds the environment (the camera ray still does): the same integral, far less noise for maps with small
+   bright regions. Other integrators, constant environments and maps with fewer than three components are untouched. This library's definition (the oracle's
+   orc_set_environment_sampling restates it; device == oracle bit for bit; tests/test_environment_sampling.py also checks the two estimators' means against each
+   other). Takes effect at the next terra_scene_commit(). */
+int  terra_amd_set_environment_sampling ( HTerraScene scene, int on );
+int  terra_amd_get_environment_sampling ( HTerraScene scene );
+
 /* Work counters of the device path, summed over all launches since the last
    reset. They define the algorithmic bytes of the roofline:
    bytes = 64*nodes + 36*tri_tests + hits*(36+60) + 12*attr_fetches + 44*pixels.

@@ -97,6 +97,9 @@ typedef struct {
     uint64_t     frame_seed;
     int          env_lighting;   /* extension, off by default: see orc_set_environment_lighting */
     int          sampler_integration;   /* extension, off by default: see orc_set_sampler_integration */
+    int          env_sampling;          /* extension, off by default: see orc_set_environment_sampling */
+    /* the lat-long environment map as a TerraDistribution2D (src/Terra.c:812-846), rebuilt by orc_scene_commit while env_sampling is on */
+    float*       env_f; float* env_cdf; float* env_row_f; float* env_row_cdf; float env_integral; size_t env_nx, env_ny;
 } OrcScene;
 
 typedef struct { v3 origin, direction, inv_direction; } OrcRay;            /* reference src/TerraPrivate.h:107-111 */
@@ -942,6 +945,68 @@ static void light_sample_triangle ( const OrcScene* s, const OrcLight* l, size_t
 /* ------------------------------------------------------------------------- */
 /* A9: integrators (reference src/Terra.c:1099-1587)                           */
 /* ------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------- */
+/* Environment importance sampling (extension, UNPINNED: nothing  */
+/* in the reference calls TerraDistribution2D, src/Terra.c:812-846; this wiring */
+/* is this repo's definition). Table: one value per texel of the lat-long map,  */
+/* luminance x sin(theta of the texel row's centre), laid out row by row and    */
+/* initialised exactly as terra_distribution_2d_init does (running float sums). */
+/* ------------------------------------------------------------------------- */
+static void env_table_free ( OrcScene* s ) {
+    free ( s->env_f ); free ( s->env_cdf ); free ( s->env_row_f ); free ( s->env_row_cdf );
+    s->env_f = s->env_cdf = s->env_row_f = s->env_row_cdf = NULL; s->env_nx = s->env_ny = 0; s->env_integral = 0;
+}
+static void env_table_build ( OrcScene* s ) {
+    env_table_free ( s );
+    const TerraAttribute* env = &s->opts.environment_map;
+    if ( !s->env_sampling || !s->env_lighting || env->state == NULL || env->eval != orc_texture_sample_latlong ) return;
+    TerraTexture* t = ( TerraTexture* ) env->state;
+    const size_t nx = t->width, ny = t->height;
+    if ( !t->pixels || nx == 0 || ny == 0 || t->components < 3 ) return;
+    s->env_f = ( float* ) malloc ( sizeof ( float ) * nx * ny ); s->env_cdf = ( float* ) malloc ( sizeof ( float ) * nx * ny );
+    s->env_row_f = ( float* ) malloc ( sizeof ( float ) * ny ); s->env_row_cdf = ( float* ) malloc ( sizeof ( float ) * ny );
+    for ( size_t y = 0; y < ny; ++y ) {
+        const float sin_row = sinf ( ( ( float ) y + 0.5f ) / ( float ) ny * terra_PI );          /* libm on the host, in the product too */
+        for ( size_t x = 0; x < nx; ++x ) {
+            v3 c = orc_texture_read ( t, x, y );
+            float lum = 0.2126f * c.x; lum += 0.7152f * c.y; lum += 0.0722f * c.z;
+            s->env_f[y * nx + x] = lum * sin_row;
+        }
+        s->env_row_f[y] = dist1d_init ( s->env_f + y * nx, nx, s->env_cdf + y * nx );
+    }
+    s->env_integral = dist1d_init ( s->env_row_f, ny, s->env_row_cdf );
+    s->env_nx = nx; s->env_ny = ny;
+}
+/* One environment sample at a shaded point (Direct and Direct+MIS, after their own light samples): two draws of stream B pick a texel through the table
+   (e1: the row, e2: the column inside it); the direction is the inverse of the lookup's mapping (src/Terra.c:468-477: theta = v terra_PI, phi = u 2 terra_PI -
+   terra_PI); density over the sphere = texel probability x texels / (2 terra_PI^2 sin theta); the sample counts when the direction is in the upper
+   hemisphere of the shading normal and its shadow ray leaves the scene; radiance = the chosen texel. Returns the term before the path throughput. */
+static v3 environment_light_sample ( const OrcScene* s, const TerraObject* obj, const TerraShadingSurface* sf, v3 p, v3 wo ) {
+    const v3 zero = v3_set ( 0, 0, 0 );
+    float e1 = randf(), e2 = randf();
+    float p_row = 0.f, p_col = 0.f; uint32_t row = 0, col = 0;
+    float sv = dist1d_sample ( s->env_row_f, s->env_row_cdf, s->env_ny, s->env_integral, e1, &p_row, &row );
+    if ( sv == FLT_MAX ) return zero;
+    float su = dist1d_sample ( s->env_f + s->env_nx * row, s->env_cdf + s->env_nx * row, s->env_nx, s->env_row_f[row], e2, &p_col, &col );
+    if ( su == FLT_MAX ) return zero;
+    float theta = sv * terra_PI, phi = su * ( 2 * terra_PI ) - terra_PI;
+    float st = orc_math_sinf ( theta ), ct = orc_math_cosf ( theta ), sp = orc_math_sinf ( phi ), cp = orc_math_cosf ( phi );
+    if ( ! ( st > 0 ) ) return zero;
+    v3 wi = v3_set ( st * cp, ct, st * sp );
+    float cosine = v3_dot ( wi, sf->normal );
+    if ( ! ( cosine > 0 ) ) return zero;
+    float pdf = ( p_row * p_col ) * ( ( float ) s->env_nx * ( float ) s->env_ny ) / ( 2 * terra_PI * terra_PI * st );
+    if ( ! ( pdf > 0 ) ) return zero;
+    TerraShadingSurface lsf; v3 ip;
+    OrcRay r = surface_ray ( sf, p, wi, 1 );
+    if ( scene_raycast ( s, &r, &lsf, &ip, NULL ) >= 0 ) return zero;
+    v3 L = orc_texture_read ( ( TerraTexture* ) s->opts.environment_map.state, col, row );
+    v3 f = obj->material.bsdf.eval ( sf, &wi, &wo );
+    return v3_scale ( v3_mul ( L, f ), cosine / pdf );
+}
+static inline bool env_sampling_active ( const OrcScene* s ) { return s->env_f != NULL; }
+
 static v3 integrate_simple ( v3 throughput, const TerraShadingSurface* sf, v3 wo ) {
     if ( v3_dot ( wo, sf->normal ) > 0 ) return v3_mul ( sf->emissive, throughput );
     return v3_set ( 0, 0, 0 );
@@ -975,6 +1040,7 @@ static v3 integrate_direct ( const OrcScene* s, const TerraObject* obj, const Te
             Lo = v3_add ( Lo, Ld );
         }
     }
+    if ( env_sampling_active ( s ) ) Lo = v3_add ( Lo, environment_light_sample ( s, obj, sf, p, wo ) );
     return v3_mul ( Lo, throughput );
 }
 
@@ -1037,6 +1103,7 @@ static v3 integrate_mis ( const OrcScene* s, const TerraObject* obj, const Terra
             }
         }
     }
+    if ( !debug_weights && env_sampling_active ( s ) ) Lo = v3_add ( Lo, environment_light_sample ( s, obj, sf, p, wo ) );
     return v3_mul ( Lo, throughput );
 }
 
@@ -1085,7 +1152,9 @@ static v3 trace ( const OrcScene* s, const OrcRay* primary, const float* first_p
         TerraShadingSurface sf; v3 p;
         int oi = scene_raycast ( s, &ray, &sf, &p, NULL );
         if ( oi < 0 ) {              /* the reference scales the throughput by the environment and then discards it (:1053-1058) */
-            if ( s->env_lighting ) { /* extension: what the commented-out "Lo += throughput" (:1056) would add */
+            /* (with environment sampling in a light integrator the environment reaches the path through the samples taken at its hits: only the camera ray adds it here) */
+            const bool env_by_samples = env_sampling_active ( s ) && ( s->opts.integrator == kTerraIntegratorDirect || s->opts.integrator == kTerraIntegratorDirectMis );
+            if ( s->env_lighting && ( bounce == 0 || !env_by_samples ) ) { /* extension: what the commented-out "Lo += throughput" (:1056) would add */
                 v3 env = attribute_eval ( &s->opts.environment_map, &ray.direction, &p );
                 throughput = v3_mul ( throughput, env );
                 Lo = v3_add ( Lo, throughput );
@@ -1243,8 +1312,9 @@ void orc_render ( const TerraCamera* cam, HTerraScene h, const TerraFramebuffer*
     orc_render_pixels ( cam, h, fb, x, y, w, hgt, ( ( OrcScene* ) h )->frame_seed, NULL );
 }
 void orc_set_frame_seed ( HTerraScene h, uint64_t seed ) { ( ( OrcScene* ) h )->frame_seed = seed; }
-void orc_set_environment_lighting ( HTerraScene h, int on ) { ( ( OrcScene* ) h )->env_lighting = on != 0; }
+void orc_set_environment_lighting ( HTerraScene h, int on ) { OrcScene* s = ( OrcScene* ) h; s->env_lighting = on != 0; env_table_build ( s ); }
 void orc_set_sampler_integration ( HTerraScene h, int on ) { ( ( OrcScene* ) h )->sampler_integration = on != 0; }
+void orc_set_environment_sampling ( HTerraScene h, int on ) { OrcScene* s = ( OrcScene* ) h; s->env_sampling = on != 0; env_table_build ( s ); }
 
 /* ------------------------------------------------------------------------- */
 /* scene lifecycle (reference src/Terra.c:130-282)                             */
@@ -1304,6 +1374,7 @@ void orc_scene_commit ( HTerraScene h ) {
         }
     }
     s->dirty_objects = false; s->dirty_lights = false;
+    env_table_build ( s );
 }
 void orc_scene_clear ( HTerraScene h ) {
     OrcScene* s = ( OrcScene* ) h;
@@ -1316,6 +1387,7 @@ void orc_scene_destroy ( HTerraScene h ) {
     OrcScene* s = ( OrcScene* ) h;
     if ( !s ) return;
     orc_scene_clear ( h );
+    env_table_free ( s );
     free ( s->objects ); free ( s->lights ); bvh_destroy ( s ); free ( s );
 }
 size_t orc_lights_count ( HTerraScene h ) { return ( ( OrcScene* ) h )->lights_pop; }

@@ -73,6 +73,11 @@ void     orc_set_environment_lighting ( HTerraScene scene, int on );
    stratified sampling method, camera sample n of a pixel takes element n of the pixel's sampler and uses it as the first two variates of the BSDF sample at
    bounce 0. The product's switch of the same name (terra_amd_set_sampler_integration) does the same, bit for bit. */
 void     orc_set_sampler_integration ( HTerraScene scene, int on );
+/* Extension, off by default, UNPINNED (nothing in the reference calls TerraDistribution2D, src/Terra.c:812-846): with environment lighting on and a lat-long
+   environment texture, the Direct and Direct+MIS integrators take one environment sample per shaded hit through a TerraDistribution2D over the map's
+   luminance x sin(theta) (two more draws of stream B, a shadow ray), and a path ray that leaves the scene after bounce 0 no longer adds the environment.
+   Takes effect at the next orc_scene_commit (or at once on a committed scene). The product's terra_amd_set_environment_sampling does the same, bit for bit. */
+void     orc_set_environment_sampling ( HTerraScene scene, int on );
 
 /* work counters accumulated by every raycast since the last reset (thread-safe sums) */
 typedef struct {

@@ -131,6 +131,11 @@ struct DevScene {
     int32_t  env_mode;
     int32_t  env_tex;
     float    env_color[3];
+    // environment importance sampling (terra_amd_set_environment_sampling; compiled into the KINDS & TERRA_KIND_SAMPLER variants only): the lat-long map textures[env_tex]
+    // as a TerraDistribution2D (reference src/Terra.c:812-846) over luminance x sin(theta of the row): env_f / env_cdf = the env_nx x env_ny table and each row's
+    // normalised running sum, env_row_f / env_row_cdf = the rows' totals and their normalised running sum, env_integral = the total. env_nx == 0: off.
+    const float* env_f; const float* env_cdf; const float* env_row_f; const float* env_row_cdf;
+    uint32_t env_nx, env_ny; float env_integral; uint32_t env_monotone;
 };
 // bit of the kernels' KINDS mask (bits 0-3 = DevBsdfKind present) that compiles the environment term in
 #define TERRA_KIND_ENV 16

@@ -621,7 +621,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) path_apply_sampler ( pd, sp, bounce );
                 end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                 if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }      // surface_ray ( sf, h.point, wi, 1.f ): its make_ray is the one at the top of this block
-            } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
+            } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode && !env_reaches_by_samples<INTEGRATOR, KINDS> ( T.sc, bounce ) ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
                 throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
                 lo_add ( throughput );
             }

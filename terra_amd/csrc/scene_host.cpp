@@ -280,6 +280,8 @@ struct Scene {
     uint32_t sample_split = 1;          // terra_amd_set_sample_split: chunks a call's samples are cut into (lanes per pixel)
     bool env_lighting = false;          // terra_amd_set_environment_lighting: escaping rays add throughput * environment
     bool work_counters = false;         // terra_amd_set_work_counters: the render kernels count rays / nodes / tests / hits / draws (instrumentation, off by default)
+    bool env_sampling = false;          // terra_amd_set_environment_sampling: Direct / Direct+MIS sample a lat-long environment through a TerraDistribution2D (built at commit)
+    float* d_env_dist = nullptr;        // its tables on the device (own allocation)
     bool sampler_integration = false;   // terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce (a launch parameter)
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
@@ -363,18 +365,25 @@ extern "C" int terra_amd_set_environment_lighting ( HTerraScene h, int on ) {
 extern "C" int terra_amd_get_environment_lighting ( HTerraScene h ) { return S ( h )->env_lighting ? 1 : 0; }
 extern "C" int terra_amd_set_work_counters ( HTerraScene h, int on ) { S ( h )->work_counters = on != 0; return 0; }
 extern "C" int terra_amd_get_work_counters ( HTerraScene h ) { return S ( h )->work_counters ? 1 : 0; }
+extern "C" int terra_amd_set_environment_sampling ( HTerraScene h, int on ) {
+    Scene* s = S ( h ); if ( !s ) return fail ( kTerraAmdErrBadArgument, "null scene" );
+    if ( s->env_sampling != ( on != 0 ) ) { s->env_sampling = on != 0; s->dirty_lights = true; s->committed = false; }
+    return 0;
+}
+extern "C" int terra_amd_get_environment_sampling ( HTerraScene h ) { return S ( h )->env_sampling ? 1 : 0; }
 extern "C" int terra_amd_set_sampler_integration ( HTerraScene h, int on ) { S ( h )->sampler_integration = on != 0; return 0; }
 extern "C" int terra_amd_get_sampler_integration ( HTerraScene h ) { return S ( h )->sampler_integration ? 1 : 0; }
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
 extern "C" uint64_t terra_amd_get_frame_seed ( HTerraScene h ) { return S ( h )->frame_seed; }
 
 static void release_device ( Scene* s ) {
-    if ( s->d_blob || s->d_counters ) {
+    if ( s->d_blob || s->d_counters || s->d_env_dist ) {
         ( void ) hipSetDevice ( s->device );
+        if ( s->d_env_dist ) ( void ) hipFree ( s->d_env_dist );
         if ( s->d_blob ) ( void ) hipFree ( s->d_blob );
         if ( s->d_counters ) ( void ) hipFree ( s->d_counters );
     }
-    s->d_blob = nullptr; s->d_counters = nullptr; s->d_bytes = 0; s->device_ok = false;
+    s->d_blob = nullptr; s->d_counters = nullptr; s->d_env_dist = nullptr; s->d_bytes = 0; s->device_ok = false;
     memset ( &s->dev, 0, sizeof s->dev );
 }
 extern "C" void terra_scene_clear ( HTerraScene h ) {
@@ -890,6 +899,37 @@ static int upload_scene ( Scene* s ) {
     s->dev.ref_replay = s->dev.reach ? ( const DevReplay* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
     s->dev.sincos24 = sincos_table_of ( s->device );
+    // environment importance sampling (extension, UNPINNED; the oracle's env_table_build restates it): the map as the reference's TerraDistribution2D would hold it
+    // (terra_distribution_2d_init, src/Terra.c:812-829: per row a running float sum in index order divided by its total, then the same over the rows' totals)
+    if ( s->env_sampling && env_mode == 2 && textures[env_tex]->components >= 3 ) {        // (the table reads three components per texel)
+        TerraTexture* t = const_cast<TerraTexture*> ( textures[env_tex] );
+        const size_t nx = t->width, ny = t->height, cells = nx * ny;
+        std::vector<float> tab ( 2 * cells + 2 * ny );
+        float* f = tab.data(), * cdf = f + cells, * row_f = cdf + cells, * row_cdf = row_f + ny;
+        bool mono = true;
+        auto row_init = [&mono] ( const float* v, size_t n, float* c ) {
+            float integral = 0.f;
+            for ( size_t i = 0; i < n; ++i ) { mono = mono && v[i] >= 0.f; integral += v[i]; c[i] = integral; }
+            for ( size_t i = 0; i < n; ++i ) c[i] /= integral;
+            return integral;
+        };
+        for ( size_t y = 0; y < ny; ++y ) {
+            const float sin_row = sinf ( ( ( float ) y + 0.5f ) / ( float ) ny * terra_PI );
+            for ( size_t x = 0; x < nx; ++x ) {
+                const TerraFloat3 c = terra_texture_read ( t, x, y );
+                float lum = 0.2126f * c.x; lum += 0.7152f * c.y; lum += 0.0722f * c.z;
+                f[y * nx + x] = lum * sin_row;
+            }
+            row_f[y] = row_init ( f + y * nx, nx, cdf + y * nx );
+        }
+        const float integral = row_init ( row_f, ny, row_cdf );
+        HIP_TRY ( hipMalloc ( ( void** ) &s->d_env_dist, tab.size() * sizeof ( float ) ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemcpy ( s->d_env_dist, tab.data(), tab.size() * sizeof ( float ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        s->d_bytes += tab.size() * sizeof ( float );
+        s->dev.env_f = s->d_env_dist; s->dev.env_cdf = s->d_env_dist + cells; s->dev.env_row_f = s->d_env_dist + 2 * cells; s->dev.env_row_cdf = s->d_env_dist + 2 * cells + ny;
+        s->dev.env_nx = ( uint32_t ) nx; s->dev.env_ny = ( uint32_t ) ny; s->dev.env_integral = integral;
+        s->dev.env_monotone = ( mono && integral > 0.f && integral <= FLT_MAX ) ? 1u : 0u;      // then every running sum is non-decreasing: bisection finds the scan's bucket
+    }
     s->device_ok = true;
     return 0;
 }
@@ -1050,6 +1090,9 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodHalton ) p.sampler_mode = 1;
     if ( s->sampler_integration && s->opts.sampling_method == kTerraSamplingMethodStratified && s->opts.strata > 0 ) p.sampler_mode = 2;
     if ( p.sampler_mode ) p.bsdf_kinds |= TERRA_KIND_SAMPLER;
+    // environment sampling lives in the same kernel variant; it only acts in the two integrators that sample lights
+    if ( s->dev.env_nx && ( p.integrator == kTerraIntegratorDirect || p.integrator == kTerraIntegratorDirectMis ) ) p.bsdf_kinds |= TERRA_KIND_SAMPLER;
+    else { p.scene.env_nx = 0; p.scene.env_ny = 0; }
     p.count_level = s->work_counters ? 2 : 0;
     return 0;
 }

@@ -1080,6 +1080,50 @@ TD LightSample draw_light_sample ( const DevScene& sc, Pcg32& rb, Counters& c, c
     return ls;
 }
 
+// -----------------------------------------------------------------------------
+// Environment importance sampling (extension, UNPINNED: nothing in the reference calls its TerraDistribution2D, src/Terra.c:812-846 -- the wiring is this
+// repo's definition, restated by the oracle's environment_light_sample). One sample per shaded hit of Direct / Direct+MIS, after their own light samples: two draws of
+// stream B pick a texel of the lat-long map through the table (e1: the row, e2: the column inside it; terra_distribution_2d_sample's arithmetic); the direction is the
+// inverse of the lookup's mapping (src/Terra.c:468-477: theta = v terra_PI, phi = u 2 terra_PI - terra_PI); density over the sphere = texel probability x texels /
+// (2 terra_PI^2 sin theta); the sample counts when the direction is in the upper hemisphere of the shading normal and its shadow ray leaves the scene; radiance = the
+// chosen texel. Returns the term before the path throughput. Compiled into the KINDS & TERRA_KIND_SAMPLER kernels only.
+// -----------------------------------------------------------------------------
+TD bool env_sampling_active ( const DevScene& sc ) { return sc.env_nx != 0u; }
+// with environment sampling in a light integrator the environment reaches a path through the samples taken at its hits: only the camera ray adds it on leaving the scene
+template <int INTEGRATOR, int KINDS>
+TD bool env_reaches_by_samples ( const DevScene& sc, uint32_t bounce ) {
+    if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 && ( INTEGRATOR == 1 || INTEGRATOR == 2 ) ) return bounce != 0u && env_sampling_active ( sc );
+    return false;
+}
+template <int COUNT, int MODE, int KINDS>
+TD V3 environment_light_sample ( const Tracer& T, Surface& sf, V3 p, V3 wo, Pcg32& rb, Counters& c ) {
+    const DevScene& sc = T.sc;
+    const V3 zero = v3 ( 0, 0, 0 );
+    const float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT );
+    float p_row = 0.f, p_col = 0.f; uint32_t row = 0, col = 0;
+    DevDistribution1D rows = { sc.env_row_f, sc.env_row_cdf, sc.env_ny, sc.env_integral, sc.env_monotone };
+    const float sv = distribution_sample ( rows, e1, &p_row, &row );
+    if ( sv == FLT_MAX ) return zero;
+    DevDistribution1D cols = { sc.env_f + ( size_t ) sc.env_nx * row, sc.env_cdf + ( size_t ) sc.env_nx * row, sc.env_nx, sc.env_row_f[row], sc.env_monotone };
+    const float su = distribution_sample ( cols, e2, &p_col, &col );
+    if ( su == FLT_MAX ) return zero;
+    const float theta = sv * TERRA_PI_F, phi = su * ( 2 * TERRA_PI_F ) - TERRA_PI_F;
+    const float st = tdm_sinf ( theta ), ct = tdm_cosf ( theta ), sp = tdm_sinf ( phi ), cp = tdm_cosf ( phi );
+    if ( ! ( st > 0.f ) ) return zero;
+    const V3 wi = v3 ( st * cp, ct, st * sp );
+    const float cosine = dot ( wi, sf.normal );
+    if ( ! ( cosine > 0.f ) ) return zero;
+    const float pdf = ( p_row * p_col ) * ( ( float ) sc.env_nx * ( float ) sc.env_ny ) / ( 2 * TERRA_PI_F * TERRA_PI_F * st );
+    if ( ! ( pdf > 0.f ) ) return zero;
+    Surface lsf;
+    Ray r = surface_ray ( sf, p, wi, 1.f );
+    RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, r, lsf, c );
+    if ( h.hit ) return zero;
+    const V3 L = texture_read ( sc.textures[sc.env_tex], col, row );
+    const V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
+    return had ( L, f ) * ( cosine / pdf );
+}
+
 template <int COUNT, int MODE, int KINDS>
 TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c ) {
     const DevScene& sc = T.sc;
@@ -1101,6 +1145,7 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
             Lo = Lo + Ld;
         }
     }
+    if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) { if ( env_sampling_active ( sc ) ) Lo = Lo + environment_light_sample<COUNT, MODE, KINDS> ( T, sf, p, wo, rb, c ); }
     return had ( Lo, throughput );
 }
 
@@ -1256,6 +1301,7 @@ TD V3 integrate_mis ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, 
             }
         }
     }
+    if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 && !DEBUG_WEIGHTS ) { if ( env_sampling_active ( sc ) ) Lo = Lo + environment_light_sample<COUNT, MODE, KINDS> ( T, sf, p, wo, rb, c ); }
     return had ( Lo, throughput );
 }
 
@@ -1365,7 +1411,7 @@ TD V3 trace_path ( const Tracer& T, Ray ray, uint32_t bounces, Pcg32& rb, Counte
         Surface sf;
         RaycastResult h = scene_raycast<COUNT, MODE, KINDS> ( T, ray, sf, c );
         if ( !h.hit ) {
-            if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
+            if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode && !env_reaches_by_samples<INTEGRATOR, KINDS> ( T.sc, bounce ) ) { throughput = had ( throughput, environment_eval ( T.sc, ray.d ) ); Lo = Lo + throughput; }
             break;
         }
         V3 wo = neg ( ray.d );

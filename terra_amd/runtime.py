@@ -65,6 +65,8 @@ _EXTRA = {
     "terra_amd_get_work_counters": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sampler_integration": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_sampler_integration": (C.c_int, [C.c_void_p]),
+    "terra_amd_set_environment_sampling": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_get_environment_sampling": (C.c_int, [C.c_void_p]),
     "terra_amd_get_frame_seed": (C.c_uint64, [C.c_void_p]),
     "terra_amd_set_tree_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_tree_mode": (C.c_int, [C.c_void_p]),

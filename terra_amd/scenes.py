@@ -71,6 +71,7 @@ class SceneDesc:
     environment: tuple = (0.0, 0.0, 0.0)
     environment_texture: Optional["TextureDesc"] = None   # lat-long map bound with terra_attribute_init_cubemap
     environment_lighting: bool = False     # extension (terra_amd_/orc_set_environment_lighting); the reference drops the environment term
+    environment_sampling: bool = False     # extension (terra_amd_/orc_set_environment_sampling): Direct / Direct+MIS sample a lat-long environment through a TerraDistribution2D
     sampler_integration: bool = False      # extension (terra_amd_/orc_set_sampler_integration); the reference never draws from the pixel sampler it constructs
     name: str = "scene"
 
@@ -471,6 +472,11 @@ def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode=None, tree_builder=No
         sym = {"terra_": "terra_amd_set_environment_lighting", "orc_": "orc_set_environment_lighting"}[lib.prefix]
         if not lib.has(sym):
             raise ValueError("environment lighting is an extension of libterra_amd.so / the oracle; this library has no such switch")
+        lib.fn(sym, C.c_int if lib.prefix == "terra_" else None, [C.c_void_p, C.c_int])(scene, 1)
+    if d.environment_sampling:      # nothing in the reference calls its TerraDistribution2D: no such switch there
+        sym = {"terra_": "terra_amd_set_environment_sampling", "orc_": "orc_set_environment_sampling"}[lib.prefix]
+        if not lib.has(sym):
+            raise ValueError("environment sampling is an extension of libterra_amd.so / the oracle; this library has no such switch")
         lib.fn(sym, C.c_int if lib.prefix == "terra_" else None, [C.c_void_p, C.c_int])(scene, 1)
     if d.sampler_integration:       # the reference constructs the sampler and never draws from it: no such switch there
         sym = {"terra_": "terra_amd_set_sampler_integration", "orc_": "orc_set_sampler_integration"}[lib.prefix]
