@@ -606,6 +606,9 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 #ifndef TERRA_FAST_LEAF_16THS
 #define TERRA_FAST_LEAF_16THS 8
 #endif
+#ifndef TERRA_FAST_PREFIX_MODE     // how a node of the fast tree is fetched: 1 = one flat load from the staged prefix (LDS) or global memory; 0 / 2: A/B forms below
+#define TERRA_FAST_PREFIX_MODE 1
+#endif
 template <int COUNT>
 TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c, bool checked = false ) {
     // a ray parallel to an axis has an infinite inverse direction there, and inf - inf would drop that axis from the test:
@@ -634,8 +637,16 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
                 cur = DEV_CHILD_EMPTY;
                 if ( w & DEV_CHILD_LEAF ) leaf = w;
                 else {
-                    const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout
+#if TERRA_FAST_PREFIX_MODE == 0          // (A/B) no staged prefix: plain global loads
+                    float4 q0 = nodes[4 * w], q1 = nodes[4 * w + 1], q2 = nodes[4 * w + 2], q3 = nodes[4 * w + 3];
+#elif TERRA_FAST_PREFIX_MODE == 2        // (A/B) the staged prefix behind a branch: ds_read or global_load instead of flat_load
+                    float4 q0, q1, q2, q3;
+                    if ( w < T.lds_nodes ) { const float4* ls = T.l_nodes + 4 * w; q0 = ls[0]; q1 = ls[1]; q2 = ls[2]; q3 = ls[3]; }
+                    else { const float4* gs = nodes + 4 * ( size_t ) w; q0 = gs[0]; q1 = gs[1]; q2 = gs[2]; q3 = gs[3]; }
+#else
+                    const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout (one flat load serves both)
                     float4 q0 = nsrc[4 * w], q1 = nsrc[4 * w + 1], q2 = nsrc[4 * w + 2], q3 = nsrc[4 * w + 3];
+#endif
                     uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
                     if ( COUNT ) ++c.nodes;
 #if TERRA_PHASE_STATS
