@@ -52,6 +52,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts (terra_amd/runtime.py says why): the host_api block's 8 caller threads each own a stream
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (MI355X_MICROARCH.md "Execution model")
@@ -536,7 +537,6 @@ def host_api(c, d, tree, split, steps):
     128-pixel tiles (satellite/include/Config.hpp:25) dealt to 8 worker threads that call terra_render() concurrently
     (satellite/src/Renderer.cpp:70-98,316-350), with the sample split chosen per call (terra_amd_set_sample_split 0) so that a
     tile-sized call still fills the GPU. Reported beside `value`, never as it."""
-    import threading
     from terra_amd import api, runtime, scenes
     lib = c.lib
     lib.clear_error()
@@ -558,13 +558,17 @@ def host_api(c, d, tree, split, steps):
     tiles = [(x, y, min(128, d.width - x), min(128, d.height - y)) for y in range(0, d.height, 128) for x in range(0, d.width, 128)]
     runtime.check(lib.set_sample_split(scene, 0))
 
+    # 8 persistent workers, as the client's job system keeps them (satellite/src/Renderer.cpp:70-98): a worker's stream and staging buffers live as long as it does
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=8)
+
     def tile_loop():
         def worker(k):
             for t in tiles[k::8]:
                 lib.render(C.byref(cam), scene, C.byref(fb.fb), *t)
-        ths = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
-        [th.start() for th in ths]; [th.join() for th in ths]
+        list(pool.map(worker, range(8)))
     dt = timed(tile_loop)
+    pool.shutdown()
     out["tile_loop_128px_8_threads"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "tiles": len(tiles), "sample_split": "automatic per call"}
     err = runtime.last_error()
     buf = C.create_string_buffer(256)

@@ -1115,7 +1115,9 @@ static void account_launch ( Scene* s, const DevRenderParams& p ) {
 // One render of p on `stream`: the render kernel sums every (pixel, chunk) job into a stream-ordered scratch buffer (persistent grid,
 // jobs handed out through a queue word at the head of that buffer; render_kernels.hip "jobs"), then the resolve kernel folds the chunk
 // sums into the pixels in chunk order and tonemaps (DevRenderParams::split; split == 1: one chunk per pixel).
-static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
+struct ThreadSlot;
+static void* slot_scratch ( ThreadSlot* slot, size_t bytes );
+static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, ThreadSlot* slot = nullptr ) {
     uint32_t split = s->sample_split;
     const uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return 0;
@@ -1124,7 +1126,8 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
         // a handful of jobs each ends with its last jobs ramping down alone (hall 1080p 256 spp: split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms); a small tile wants
         // the split to fill the GPU at all. Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
         split = 1;
-        while ( split < 16 && ( uint64_t ) blocks * split < 61440 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
+        // (up to 32 lanes per pixel: the reference client's 128-pixel tiles at 512 spp, called from 8 threads, 69.1 -> 66.7 ms per frame with 32 instead of 16)
+        while ( split < 32 && ( uint64_t ) blocks * split < 61440 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
     }
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
     if ( split < 1 ) split = 1;
@@ -1135,8 +1138,10 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
         pool_device = s->device;
     }
     const size_t header = 256;                                     // the job queue word (+ padding that keeps the partials 256-byte aligned)
-    void* scratch = nullptr;
-    HIP_TRY ( hipMallocAsync ( &scratch, header + ( size_t ) split * blocks * 256 * sizeof ( float4 ), stream ), kTerraAmdErrNoDevice );
+    const size_t scratch_bytes = header + ( size_t ) split * blocks * 256 * sizeof ( float4 );
+    void* scratch = slot ? slot_scratch ( slot, scratch_bytes ) : nullptr;
+    const bool pooled = scratch == nullptr;
+    if ( pooled ) HIP_TRY ( hipMallocAsync ( &scratch, scratch_bytes, stream ), kTerraAmdErrNoDevice );
     hipError_t e = hipMemsetAsync ( scratch, 0, header, stream );
     p.split = split; p.split_log2 = 0; while ( ( 1u << p.split_log2 ) < split ) ++p.split_log2;
     p.chunk_spp = p.spp / split; p.partials = ( float4* ) ( ( char* ) scratch + header );
@@ -1145,14 +1150,14 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream ) {
         const uint64_t bpt = p.tile_size / 16, bpt2 = bpt * bpt, tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size, tiles_y = ( p.h + p.tile_size - 1 ) / p.tile_size;
         auto magic = [] ( uint64_t d ) { return d <= 1 ? 0u : ( uint32_t ) ( ( ( 1ull << 32 ) + d - 1 ) / d ); };
         if ( ! ( ( uint64_t ) blocks * split * 256 < ( 1ull << 32 ) && ( uint64_t ) blocks * bpt2 < ( 1ull << 32 ) && ( tiles_x * tiles_y + p.world ) * tiles_x < ( 1ull << 32 ) && bpt2 * bpt < ( 1ull << 32 ) ) ) {
-            ( void ) hipFreeAsync ( scratch, stream );
+            if ( pooled ) ( void ) hipFreeAsync ( scratch, stream );
             return fail ( kTerraAmdErrBadArgument, "render rectangle too large for one launch (%u blocks x split %u): render it in several calls", blocks, split );
         }
         p.job_div_bpt2 = magic ( bpt2 ); p.job_div_tiles_x = magic ( tiles_x ); p.job_div_bpt = magic ( bpt ); p.job_tiles_x = ( uint32_t ) tiles_x;
     }
     if ( e == hipSuccess ) e = terra_launch_render ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_resolve ( p, stream );
-    ( void ) hipFreeAsync ( scratch, stream );
+    if ( pooled ) ( void ) hipFreeAsync ( scratch, stream );
     if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "render launch: %s", hipGetErrorString ( e ) );
     return 0;
 }
@@ -1233,22 +1238,51 @@ extern "C" int terra_amd_unpack_tiles ( void* d_pixels, void* d_results, size_t 
 // The slot is released when its thread exits.
 struct ThreadSlot {
     int device = -1; hipStream_t stream = nullptr; void* d_pixels = nullptr; void* d_results = nullptr; size_t cap_px = 0;
+    void* d_scratch = nullptr; size_t scratch_bytes = 0;      // the launch's job sums + queue word (launch_render): kept per thread so that a tile-sized call does not go through the pool
     void release() {
         if ( device < 0 ) return;
         if ( hipSetDevice ( device ) == hipSuccess ) {
             if ( stream ) { ( void ) hipStreamSynchronize ( stream ); ( void ) hipStreamDestroy ( stream ); }
             if ( d_pixels ) ( void ) hipFree ( d_pixels );
             if ( d_results ) ( void ) hipFree ( d_results );
+            if ( d_scratch ) ( void ) hipFree ( d_scratch );
         }
-        device = -1; stream = nullptr; d_pixels = d_results = nullptr; cap_px = 0;
+        device = -1; stream = nullptr; d_pixels = d_results = d_scratch = nullptr; cap_px = 0; scratch_bytes = 0;
     }
     ~ThreadSlot() { release(); }
 };
-static thread_local ThreadSlot t_slot;
+// A thread keeps its slot (stream, staging buffers, scratch) for its lifetime; a thread that ends hands the slot to the next new thread instead of freeing it:
+// clients that start fresh worker threads for every frame would otherwise pay a stream creation, three allocations and -- worse -- three hipFree, each of which
+// waits for the whole device, per thread and frame. The pool is emptied when the library is unloaded.
+// Hardware queues: ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and kernels of streams that share one run one after the other.
+// The reference's client calls terra_render() from 8 worker threads (satellite/src/Renderer.cpp:70-98), each with its own stream here, so the library asks for 8 when it is
+// loaded -- which only has an effect if that happens before the process's first HIP call, and never overrides a value the user has set (tile loop of the Cornell
+// frame, 8 threads: 69.7 -> 65.5 ms; profiles/r03_measurements/host_tile_loop.log).
+__attribute__ (( constructor )) static void terra_amd_ask_for_hw_queues() { setenv ( "GPU_MAX_HW_QUEUES", "8", 0 ); }
+struct SlotPool {
+    std::mutex lock; std::vector<ThreadSlot*> idle;
+    ThreadSlot* take() { std::lock_guard<std::mutex> g ( lock ); if ( idle.empty() ) return new ThreadSlot(); ThreadSlot* t = idle.back(); idle.pop_back(); return t; }
+    void give ( ThreadSlot* t ) { std::lock_guard<std::mutex> g ( lock ); idle.push_back ( t ); }
+    ~SlotPool() { for ( ThreadSlot* t : idle ) delete t; }
+};
+static SlotPool g_slots;
+struct SlotHolder { ThreadSlot* slot = nullptr; ThreadSlot& get() { if ( !slot ) slot = g_slots.take(); return *slot; } ~SlotHolder() { if ( slot ) g_slots.give ( slot ); } };
+static thread_local SlotHolder t_slot_holder;
+#define t_slot ( t_slot_holder.get() )
+// (the slot's stream orders its launches: a call's sums are folded before the next call of the thread overwrites them)
+static void* slot_scratch ( ThreadSlot* slot, size_t bytes ) {
+    if ( slot->scratch_bytes < bytes ) {
+        if ( slot->d_scratch ) { ( void ) hipStreamSynchronize ( slot->stream ); ( void ) hipFree ( slot->d_scratch ); slot->d_scratch = nullptr; slot->scratch_bytes = 0; }
+        if ( hipMalloc ( &slot->d_scratch, bytes ) != hipSuccess ) { ( void ) hipGetLastError(); slot->d_scratch = nullptr; return nullptr; }      // (the pool then)
+        slot->scratch_bytes = bytes;
+    }
+    return slot->d_scratch;
+}
 
 static int slot_prepare ( int device, size_t npx ) {
     ThreadSlot& t = t_slot;
-    HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );
+    int current = -1;
+    if ( hipGetDevice ( &current ) != hipSuccess || current != device ) HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );
     if ( t.device != device ) {
         t.release(); t.device = device;
         HIP_TRY ( hipStreamCreateWithFlags ( &t.stream, hipStreamNonBlocking ), kTerraAmdErrNoDevice );
@@ -1281,7 +1315,7 @@ static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffe
     char* hpix = ( char* ) fb->pixels + ( y * fb->width + x ) * 12;
     HIP_TRY ( hipMemcpy2DAsync ( t.d_results, w * 16, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, t.stream ), kTerraAmdErrLaunch );
     p.pixels = ( float* ) t.d_pixels; p.results = t.d_results; p.rand_calls = nullptr;
-    if ( int lrc = launch_render ( s, p, t.stream ) ) return lrc;
+    if ( int lrc = launch_render ( s, p, t.stream, &t ) ) return lrc;
     HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, t.d_results, w * 16, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, t.d_pixels, w * 12, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipStreamSynchronize ( t.stream ), kTerraAmdErrLaunch );

@@ -19,6 +19,10 @@ from . import api, scenes
 
 HERE = Path(__file__).resolve().parent
 import os as _os
+# 8 hardware queues instead of ROCm's default 4: terra_render() callers on 8 threads (the reference client's pattern) each own a stream, and streams that share a
+# hardware queue run their kernels one after the other. Read by the HIP runtime at its initialisation, so it is set here, before anything touches the GPU; the
+# library asks for the same when it is loaded on its own (scene_host.cpp). A value the user has set wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = Path(_os.environ.get("TERRA_AMD_LIB", HERE / "libterra_amd.so"))     # TERRA_AMD_LIB: experiment builds (terra_amd/build.py --variant)
 
 _lib: Optional[api.TerraLib] = None
