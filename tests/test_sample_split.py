@@ -151,9 +151,41 @@ def test_threaded_tile_calls_with_automatic_split(H, L):
         fb.destroy(); L.scene_destroy(scene)
     L.clear_first_error(); L.clear_error()
     th = threading.Thread(target=probe); th.start(); th.join()
-    assert seen["bytes"] == 64 * 48 * 28
+    assert seen["bytes"] >= 64 * 48 * 28 and seen["bytes"] < d.width * d.height * 28       # (a new thread may inherit the slot of a worker that has ended: never smaller than its own largest tile)
     assert runtime.last_error() == "" and "bad tile rectangle" in runtime.first_error()[1]
     L.clear_first_error()
     # a 64x48 tile is 12 blocks: the automatic rule gives 4 lanes per pixel at 64 spp (16 samples each) = 4 calls of 16
     want = dev(L, scenes.cornell_box(192, 128, 16, integrator=api.kTerraIntegratorDirect), passes=4)
     assert np.array_equal(frames[0][0].view(np.uint32), want["acc"].view(np.uint32))
+
+
+def test_short_lived_worker_threads_hand_their_slots_on(H, L):
+    """a client that starts fresh worker threads for every frame: a thread that ends hands its stream and buffers to the next new thread
+    (scene_host.cpp SlotPool); three generations of workers accumulate three passes, identical to three device-resident passes"""
+    import threading
+    d = scenes.cornell_box(160, 96, 8)
+    tiles = [(x, y, min(48, d.width - x), min(32, d.height - y)) for y in range(0, d.height, 32) for x in range(0, d.width, 48)]
+    scene = scenes.build_scene(L, d); assert L.set_sample_split(scene, 0) == 0
+    fb = api.Framebuffer(L, d.width, d.height); cam = scenes.camera_of(d)
+    L.clear_error(); L.clear_first_error()
+    sizes = []
+    for generation in range(3):
+        def work(k):
+            for t in tiles[k::5]:
+                L.render(C.byref(cam), scene, C.byref(fb.fb), *t)
+            sizes.append(L.thread_staging_bytes())
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(5)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+    assert runtime.last_error() == "" and runtime.first_error()[0] == 0
+    assert min(sizes) >= 48 * 32 * 28
+    got = (fb.results["acc"].copy(), fb.results["samples"].copy())
+    fb.destroy(); L.scene_destroy(scene)
+    assert (got[1] == 24).all()
+    # reference: the same 3 x tiles calls from this one thread
+    scene = scenes.build_scene(L, d); assert L.set_sample_split(scene, 0) == 0
+    fb = api.Framebuffer(L, d.width, d.height)
+    for generation in range(3):
+        for t in tiles:
+            L.render(C.byref(cam), scene, C.byref(fb.fb), *t)
+    assert np.array_equal(fb.results["acc"].view(np.uint32), got[0].view(np.uint32))
+    fb.destroy(); L.scene_destroy(scene)
