@@ -14,6 +14,7 @@ from terra_amd import api, runtime, scenes
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SCALE = float(os.environ.get("FUZZ_SCALE", "1"))       # multiplies every coordinate (scene and camera): the 1e-4 box margins do not scale with it
+EXT = os.environ.get("FUZZ_EXT", "0") == "1"
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = runtime.load()
 orc = api.TerraLib(os.path.join(ROOT, "oracle", "liboracle.so"), "orc_")
@@ -54,6 +55,16 @@ for it in range(n_iter):
     d = scenes.SceneDesc(objects=soup(n, int(rs.randint(1, 5))), width=W, height=H, spp=spp, bounces=int(rs.randint(0, 6)), integrator=integ,
                          camera_position=(0.0, 0.0, -6.0 * SCALE), tonemap=int(rs.randint(0, 5)), environment=(0.2, 0.3, 0.4), environment_lighting=bool(rs.randint(2)),
                          jitter=float(rs.choice([0.0, 0.5])))      # jitter 0 on odd frame sizes gives rays with exactly zero direction components (the exact slab path)
+    if EXT:     # FUZZ_EXT=1: the unpinned extensions too -- a lat-long environment texture, environment importance sampling, the pixel sampler feeding bounce 0
+        if rs.randint(2):
+            th, tw = int(rs.randint(1, 12)), int(rs.randint(1, 20))
+            tex = rs.uniform(0, 3, size=(th, tw, 3)).astype(np.float32) if rs.randint(2) else rs.randint(0, 256, size=(th, tw, 3)).astype(np.uint8)
+            if rs.randint(3) == 0: tex[rs.randint(th), rs.randint(tw)] = tex.max() * (40 if tex.dtype == np.float32 else 1)
+            d.environment_texture = scenes.TextureDesc(tex, address_mode=int(rs.randint(0, 3))); d.environment_lighting = True
+            d.environment_sampling = bool(rs.randint(2))
+        m = int(rs.randint(3))
+        if m == 1: d.sampling = api.kTerraSamplingMethodHalton; d.sampler_integration = True
+        if m == 2 and split == 1: d.sampling = api.kTerraSamplingMethodStratified; d.strata = int(rs.randint(1, 4)); d.sampler_integration = bool(rs.randint(2))
     cam = scenes.camera_of(d)
     so = scenes.build_scene(orc, d); fo = api.Framebuffer(orc, W, H)
     dchunk = scenes.SceneDesc(**{**d.__dict__, "spp": spp // split}); sc = scenes.build_scene(orc, dchunk)
@@ -77,8 +88,8 @@ for it in range(n_iter):
     ok2 = bits_equal(outs[2][0], outs[0][0]) and bits_equal(outs[2][1], outs[0][1])
     if not (ok0 and ok1 and ok2):
         bad += 1; print("MISMATCH", dict(it=it, tris=n, W=W, H=H, integ=integ, split=split, spp=spp, bounces=d.bounces, tonemap=d.tonemap, env=d.environment_lighting, vs_oracle=ok0, fast_vs_ref=ok1, auto_vs_ref=ok2,
-                                         kinds=[o.material.kind for o in d.objects]))
+                                         kinds=[o.material.kind for o in d.objects], env_tex=d.environment_texture is not None, env_sampling=d.environment_sampling, sampling=d.sampling, sampler=d.sampler_integration))
     fo.destroy(); orc.scene_destroy(so); orc.scene_destroy(sc)
     if (it + 1) % 1000 == 0: print(f"  {it + 1} cases, {bad} mismatches so far", file=sys.stderr, flush=True)      # (a long silent run on the GPU box is taken for a hang)
-print(f"{n_iter} cases at scale {SCALE:g}, {bad} mismatches, {faults} bounds faults, automatic mode chose {decided}, last error: '{runtime.last_error()}'")
+print(f"{n_iter} cases at scale {SCALE:g}{' with the extensions' if EXT else ''}, {bad} mismatches, {faults} bounds faults, automatic mode chose {decided}, last error: '{runtime.last_error()}'")
 sys.exit(1 if bad or faults else 0)
