@@ -123,6 +123,7 @@ TD bool block_pixel ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint
 // would make them; split == 1: the one sum of the call, reference src/Terra.c:570-572), then exposure / tonemap / store
 // (src/Terra.c:574-630). gridDim.x = the job space's 16x16 pixel blocks.
 __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams p ) {
+    if ( p.job_queue && blockIdx.x == 0 && threadIdx.x == 0 ) *p.job_queue = 0u;       // the render kernel is done with its queue: leave the word ready for the next launch on this scratch (scene_host.cpp launch_render)
     uint32_t px, py;
     if ( !block_pixel ( p, blockIdx.x, threadIdx.x, px, py ) ) return;
     const size_t pix = ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x );

@@ -1142,7 +1142,9 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     void* scratch = slot ? slot_scratch ( slot, scratch_bytes ) : nullptr;
     const bool pooled = scratch == nullptr;
     if ( pooled ) HIP_TRY ( hipMallocAsync ( &scratch, scratch_bytes, stream ), kTerraAmdErrNoDevice );
-    hipError_t e = hipMemsetAsync ( scratch, 0, header, stream );
+    // the queue word must be zero when the render kernel starts: a slot's scratch is zeroed when it is allocated and again by every resolve kernel (one kernel less per
+    // call on the host path, whose small kernels wait behind the other callers' render grids); memory from the pool is fresh each time
+    hipError_t e = pooled ? hipMemsetAsync ( scratch, 0, header, stream ) : hipSuccess;
     p.split = split; p.split_log2 = 0; while ( ( 1u << p.split_log2 ) < split ) ++p.split_log2;
     p.chunk_spp = p.spp / split; p.partials = ( float4* ) ( ( char* ) scratch + header );
     p.job_blocks = blocks * split; p.job_queue = terra_render_wants_queue ( p ) ? ( uint32_t* ) scratch : nullptr;
@@ -1158,6 +1160,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     if ( e == hipSuccess ) e = terra_launch_render ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_resolve ( p, stream );
     if ( pooled ) ( void ) hipFreeAsync ( scratch, stream );
+    else if ( e != hipSuccess ) ( void ) hipMemsetAsync ( scratch, 0, header, stream );       // (a launch that failed half way must not leave a used queue word behind)
     if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "render launch: %s", hipGetErrorString ( e ) );
     return 0;
 }
@@ -1274,6 +1277,7 @@ static void* slot_scratch ( ThreadSlot* slot, size_t bytes ) {
     if ( slot->scratch_bytes < bytes ) {
         if ( slot->d_scratch ) { ( void ) hipStreamSynchronize ( slot->stream ); ( void ) hipFree ( slot->d_scratch ); slot->d_scratch = nullptr; slot->scratch_bytes = 0; }
         if ( hipMalloc ( &slot->d_scratch, bytes ) != hipSuccess ) { ( void ) hipGetLastError(); slot->d_scratch = nullptr; return nullptr; }      // (the pool then)
+        if ( hipMemset ( slot->d_scratch, 0, 256 ) != hipSuccess ) { ( void ) hipGetLastError(); ( void ) hipFree ( slot->d_scratch ); slot->d_scratch = nullptr; return nullptr; }
         slot->scratch_bytes = bytes;
     }
     return slot->d_scratch;
