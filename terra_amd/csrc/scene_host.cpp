@@ -1288,7 +1288,9 @@ static int slot_prepare ( int device, size_t npx ) {
     int current = -1;
     if ( hipGetDevice ( &current ) != hipSuccess || current != device ) HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );
     if ( t.device != device ) {
+        const bool had_other = t.device >= 0;
         t.release(); t.device = device;
+        if ( had_other ) HIP_TRY ( hipSetDevice ( device ), kTerraAmdErrNoDevice );      // (release() made the slot's old device current)
         HIP_TRY ( hipStreamCreateWithFlags ( &t.stream, hipStreamNonBlocking ), kTerraAmdErrNoDevice );
     }
     if ( t.cap_px < npx ) {
