@@ -748,10 +748,16 @@ static hipError_t launch_kinds ( const DevRenderParams& p, size_t lds, hipStream
 }
 // kinds present in the scene -> the leanest compiled variant that covers them: diffuse only (1), diffuse + Phong (3: what
 // OBJ/MTL scenes map to, satellite/src/Scene.cpp:193-230), everything (GGX, glass, textures, environment term), or everything + the sampler integration
+#ifndef TERRA_KINDS_PRESETS_VARIANT
+#define TERRA_KINDS_PRESETS_VARIANT 1
+#endif
 template <int I, int MODE>
 static hipError_t launch_mode ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
     if ( p.bsdf_kinds == 1 ) return launch_kinds<I, MODE, 1> ( p, lds, stream );
     if ( ( p.bsdf_kinds & ~3u ) == 0 ) return launch_kinds<I, MODE, 3> ( p, lds, stream );
+    if constexpr ( TERRA_KINDS_PRESETS_VARIANT && I <= 2 && MODE != 0 ) {       // the four presets on constant attributes, no environment term (BASELINE config 4's sphere scene): the usual integrators, off the reference tree
+        if ( ( p.bsdf_kinds & ~15u ) == 0 ) return launch_kinds<I, MODE, 15> ( p, lds, stream );
+    }
     if ( ( p.bsdf_kinds & TERRA_KIND_SAMPLER ) == 0 ) return launch_kinds<I, MODE, TERRA_KINDS_ALL & ~TERRA_KIND_SAMPLER> ( p, lds, stream );      // (the sampler integration costs the generic
     return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, lds, stream );                                                                            //  kernel 11 % when merely compiled in: its own variant)
 }
