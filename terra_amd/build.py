@@ -16,7 +16,11 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libterra_amd.so"
-SOURCES = ["scene_host.cpp", "tree_build.cpp", "render_kernels.hip", "unit_kernels.hip", "tree_build_device.hip"]
+# (source, object name, extra flags): render_kernels.hip is compiled once per TERRA_TU value -- its kernel instances per template MODE -- so that the units build in parallel
+SOURCES = [("scene_host.cpp", "scene_host.cpp", []), ("tree_build.cpp", "tree_build.cpp", []),
+           ("render_kernels.hip", "render_kernels.tu0.hip", ["-DTERRA_TU=0"]), ("render_kernels.hip", "render_kernels.tu1.hip", ["-DTERRA_TU=1"]),
+           ("render_kernels.hip", "render_kernels.tu2.hip", ["-DTERRA_TU=2"]), ("render_kernels.hip", "render_kernels.tu3.hip", ["-DTERRA_TU=3"]),
+           ("unit_kernels.hip", "unit_kernels.hip", []), ("tree_build_device.hip", "tree_build_device.hip", [])]
 HEADERS = ["dev_types.h", "dev_math.h", "rng.h", "trace_device.h", "sampling_device.h", "kernels.h", "tree_build.h"]
 ARCH = os.environ.get("TERRA_AMD_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -52,14 +56,14 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
     if not stamp.exists() or stamp.read_text() != flags_now:
         force = True
     jobs = []
-    for src in SOURCES:
-        obj = objdir / (src + ".o")
+    for src, name, tu_flags in SOURCES:
+        obj = objdir / (name + ".o")
         if force or _stale(obj, [CSRC / src] + deps_common):
-            jobs.append((src, obj))
+            jobs.append((src, obj, tu_flags))
 
     def compile_one(job):
-        src, obj = job
-        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", str(CSRC / src), "-o", str(obj)]
+        src, obj, tu_flags = job
+        cmd = [HIPCC, *FLAGS, *tu_flags, *extra_flags, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -73,7 +77,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(compile_one, jobs))
     stamp.write_text(flags_now)
-    objs = [objdir / (s + ".o") for s in SOURCES]
+    objs = [objdir / (name + ".o") for _, name, _ in SOURCES]
     if force or jobs or _stale(OUT, objs):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", str(OUT), *map(str, objs)]
         if verbose:

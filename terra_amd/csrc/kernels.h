@@ -4,6 +4,11 @@
 #include "dev_types.h"
 
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream );
+// (render_kernels.hip is compiled as several translation units, one per template MODE: 0 reference tree from global memory, 1 LDS-resident, 2 fast tree, 3 fast tree + reachability replay)
+hipError_t terra_launch_render_mode0 ( const DevRenderParams& p, size_t lds, hipStream_t stream );
+hipError_t terra_launch_render_mode1 ( const DevRenderParams& p, size_t lds, hipStream_t stream );
+hipError_t terra_launch_render_mode2 ( const DevRenderParams& p, size_t lds, hipStream_t stream );
+hipError_t terra_launch_render_mode3 ( const DevRenderParams& p, size_t lds, hipStream_t stream );
 bool       terra_render_wants_queue ( const DevRenderParams& p );   // the launch's loop gains from the persistent grid + job queue (render_kernels.hip "jobs")
 uint32_t   terra_render_blocks ( const DevRenderParams& p );   // 256-thread blocks of one chunk (own tiles x blocks per tile)
 hipError_t terra_launch_resolve ( const DevRenderParams& p, hipStream_t stream );   // second kernel of a split render (p.split > 1)

@@ -23,6 +23,16 @@
 #include "trace_device.h"
 #include "kernels.h"
 
+// One source, several translation units (terra_amd/build.py compiles this file once per TERRA_TU value, in parallel: a single unit takes 3 minutes):
+//   TERRA_TU 0  everything that is not a render-kernel instance (resolve / tile kernels, LDS planning, the launch dispatch) + the kernels of template MODE 0
+//   TERRA_TU 1 / 2 / 3  the kernels of template MODE 1 (LDS-resident scenes) / 2 (fast tree) / 3 (fast tree + reachability replay) and their launcher
+//   undefined   all of it in one unit (tools/kernel_resources.sh, tools/isa_cost.py)
+#ifdef TERRA_TU
+#define TERRA_TU_HAS(k) ( TERRA_TU == ( k ) )
+#else
+#define TERRA_TU_HAS(k) 1
+#endif
+
 struct DevResult { float acc[3]; int samples; };
 
 TD void wave_flush_counters ( const Counters& c, unsigned long long* g ) {
@@ -58,7 +68,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.sc = sc;
     // [staged nodes][staged triangles][staged properties][stack][leaf list][parked words]  (sizes: terra_lds_bytes)
     float4* ln = lds;                                                // byte offset 0: a staged node's address is its stack word
-    float4* lt = ln + ( MODE == 2 ? 4 : TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;      // MODE 2 stages a prefix of the fast tree as plain 64-B nodes
+    float4* lt = ln + ( MODE >= 2 ? 4 : TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;      // MODE 2 stages a prefix of the fast tree as plain 64-B nodes
     float4* lp = lt + 3 * lds_tris;
     // MODE 1 also stages what shading reads per hit: the materials, the light list and the per-triangle areas (scene_extra_lds_bytes: three 16-byte aligned sections)
     uint32_t* lm = reinterpret_cast<uint32_t*> ( lp + 4 * lds_tris );
@@ -74,7 +84,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
     const float4* gt = reinterpret_cast<const float4*> ( sc.tris );
     const float4* gp = reinterpret_cast<const float4*> ( sc.props );
-    if ( MODE == 2 ) {        // hot nodes of the fast tree: its numbering is breadth first, so the first lds_nodes nodes are its top levels
+    if ( MODE >= 2 ) {        // hot nodes of the fast tree: its numbering is breadth first, so the first lds_nodes nodes are its top levels
         const float4* fn = reinterpret_cast<const float4*> ( sc.fast_nodes );
         for ( uint32_t i = tid; i < 4 * lds_nodes; i += TERRA_COL ) ln[i] = fn[i];
     } else
@@ -119,6 +129,7 @@ TD bool block_pixel ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint
     return lx < p.w && ly < p.h;
 }
 
+#if TERRA_TU_HAS ( 0 )
 // Second kernel of every render: pixel += chunk sums, in chunk order (float adds in the order `split` successive calls
 // would make them; split == 1: the one sum of the call, reference src/Terra.c:570-572), then exposure / tonemap / store
 // (src/Terra.c:574-630). gridDim.x = the job space's 16x16 pixel blocks.
@@ -143,6 +154,8 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
     p.pixels[3 * pix + 0] = color.x; p.pixels[3 * pix + 1] = color.y; p.pixels[3 * pix + 2] = color.z;
     if ( p.rand_calls ) p.rand_calls[pix] = calls;
 }
+
+#endif
 
 // Occupancy target per integrator (second __launch_bounds__ argument = waves per SIMD = 256-thread
 // blocks per CU). Measured on MI355X (profiles/): the Simple/debug kernels run fastest at 5 even
@@ -179,7 +192,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_FAST_EXIT_16THS    // MODE 2 leaves the traversal when this many 16ths of the lanes that entered it have finished (a ray is cheap there, so shading wants fuller waves)
 #define TERRA_FAST_EXIT_16THS 12
 #endif
-#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) || ( TERRA_DECOUPLED_FAST && ( M ) == 2 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
+#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) || ( TERRA_DECOUPLED_FAST && ( M ) >= 2 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
 // ... and Direct, whose one shadow ray per hit becomes a traversal job of its own (scenes without textured attributes)
 #ifndef TERRA_DECOUPLED_DIRECT_ENABLE
 #define TERRA_DECOUPLED_DIRECT_ENABLE 1
@@ -197,11 +210,11 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_LDS_EXIT_16THS
 #define TERRA_LDS_EXIT_16THS 16
 #endif
-#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) == 2 ) || ( TERRA_DECOUPLED_LDS_DIRECT && ( M ) == 1 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) >= 2 ) || ( TERRA_DECOUPLED_LDS_DIRECT && ( M ) == 1 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_DECOUPLED_MIS_ENABLE
 #define TERRA_DECOUPLED_MIS_ENABLE 1
 #endif
-#define TERRA_DECOUPLED_MIS(I, M, K) ( TERRA_DECOUPLED_MIS_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_MIS && ( M ) == 2 ) ) && ( I ) == 2 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#define TERRA_DECOUPLED_MIS(I, M, K) ( TERRA_DECOUPLED_MIS_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_MIS && ( M ) >= 2 ) ) && ( I ) == 2 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_WAVES_DECOUPLED
 #define TERRA_WAVES_DECOUPLED TERRA_WAVES_SIMPLE
 #endif
@@ -221,7 +234,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #define TERRA_WAVES_FAST_TREE_GENERIC_LIGHT 4
 #endif
 #define TERRA_IS_LIGHT(I) ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 )
-#define TERRA_WAVES_FOR(I, K, M) ( ( M ) == 2 ? ( ( K ) == 1 ? ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_LIGHT : TERRA_WAVES_FAST_TREE ) : ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_GENERIC_LIGHT : TERRA_WAVES_FAST_TREE_GENERIC ) ) \
+#define TERRA_WAVES_FOR(I, K, M) ( ( M ) >= 2 ? ( ( K ) == 1 ? ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_LIGHT : TERRA_WAVES_FAST_TREE ) : ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_GENERIC_LIGHT : TERRA_WAVES_FAST_TREE_GENERIC ) ) \
                                  : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : ( ( I ) == 1 && ( ( K ) == 1 || ( TERRA_WAVES_DIRECT_PHONG && ( K ) == 3 ) ) ) ? TERRA_WAVES_DIRECT : TERRA_WAVES_LIGHT ) \
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
@@ -247,7 +260,7 @@ TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t
 // reached it; if not -- very rare -- the same ray goes back in flight with every candidate checked (trace_device.h bvh_traverse_fast). True = the lane is traversing again.
 template <int MODE>
 TD bool lane_traversal_recheck ( const Tracer& T, const Ray& ray, LaneTraversal& t ) {
-    if ( MODE != 2 || !T.sc.reach || !t.regular || t.best.tri == 0xffffffffu ) return false;      // (MODE 2: regular == false marks the checked pass)
+    if ( MODE != 3 || !T.sc.reach || !t.regular || t.best.tri == 0xffffffffu ) return false;      // (MODE 2: regular == false marks the checked pass)
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     if ( reference_reaches ( T, t.best.tri, r ) ) return false;
     t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.leaf = 0;
@@ -260,14 +273,14 @@ template <int COUNT, int MODE>
 TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
     const int n_trav = __popcll ( __ballot ( t.traversing ) );
     if ( n_trav == 0 ) return false;
-    int quota = MODE == 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : MODE == 1 ? ( n_trav * TERRA_LDS_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+    int quota = MODE >= 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : MODE == 1 ? ( n_trav * TERRA_LDS_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
     const int exit_active = n_trav - quota;
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
     int* sp = T.stack + t.top * TERRA_COL;
-    if constexpr ( MODE == 2 ) {
+    if constexpr ( MODE >= 2 ) {
         ClosestRanked b2; b2.depth = t.best.depth; b2.rank = t.rank; b2.tri = t.best.tri;
-        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.leaf, t.traversing, exit_active, c, T.sc.reach && !t.regular );      // (a ray with a zero direction component starts in the checked pass: harmless)
+        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.leaf, t.traversing, exit_active, c, MODE == 3 && T.sc.reach && !t.regular );      // (a ray with a zero direction component starts in the checked pass: harmless)
         t.best.depth = b2.depth; t.best.tri = b2.tri; t.rank = b2.rank;
     } else {
         if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );
@@ -280,7 +293,7 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
 // the closest hit as the index the light tables use (the soup): the fast tree's triangles are in leaf order and carry (object, triangle in object)
 template <int MODE>
 TD uint32_t hit_soup_index ( const Tracer& T, uint32_t tri ) {
-    if ( MODE != 2 || tri == 0xffffffffu ) return tri;
+    if ( MODE < 2 || tri == 0xffffffffu ) return tri;
     const float4* ft = reinterpret_cast<const float4*> ( T.sc.fast_tris );
     return T.sc.mats[__float_as_uint ( ft[3 * tri].w )].first_tri + __float_as_uint ( ft[3 * tri + 1].w );
 }
@@ -437,7 +450,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     Surface lsf; uint32_t object = 0, tri_in_object = 0, nattr = 0, tri_s = 0xffffffffu;
                     V3 point = hit ? r.o + r.d * lt.best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
                     if ( hit ) {
-                        if ( job == 2 ) { surface_init<MODE, KINDS> ( T, lt.best.tri, point, lsf, object, tri_in_object, nattr ); tri_s = MODE == 2 ? T.sc.mats[object].first_tri + tri_in_object : lt.best.tri; }
+                        if ( job == 2 ) { surface_init<MODE, KINDS> ( T, lt.best.tri, point, lsf, object, tri_in_object, nattr ); tri_s = MODE >= 2 ? T.sc.mats[object].first_tri + tri_in_object : lt.best.tri; }
                         else { tri_s = hit_soup_index<MODE> ( T, lt.best.tri ); const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * tri_s]; object = __float_as_uint ( t0.w ); nattr = T.sc.mats[object].attributes_count; }
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
@@ -648,6 +661,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
 
 // ---- launch -------------------------------------------------------------------
 
+#if TERRA_TU_HAS ( 0 )
 static uint32_t own_tiles ( uint32_t w, uint32_t h, uint32_t tile, uint32_t rank, uint32_t world ) {
     uint32_t tiles = ( ( w + tile - 1 ) / tile ) * ( ( h + tile - 1 ) / tile );
     return tiles > rank ? ( tiles - rank + world - 1 ) / world : 0;
@@ -718,6 +732,8 @@ void terra_plan_lds ( DevRenderParams& p ) {
     }
 }
 
+#endif
+
 // blocks of one kernel instance the GPU holds at once (occupancy x CUs), cached per (kernel, LDS size): the persistent grid
 static uint32_t resident_blocks ( const void* fn, size_t lds ) {
     struct Key { const void* fn; size_t lds; int dev; uint32_t blocks; };
@@ -761,13 +777,34 @@ static hipError_t launch_mode ( const DevRenderParams& p, size_t lds, hipStream_
     if ( ( p.bsdf_kinds & TERRA_KIND_SAMPLER ) == 0 ) return launch_kinds<I, MODE, TERRA_KINDS_ALL & ~TERRA_KIND_SAMPLER> ( p, lds, stream );      // (the sampler integration costs the generic
     return launch_kinds<I, MODE, TERRA_KINDS_ALL> ( p, lds, stream );                                                                            //  kernel 11 % when merely compiled in: its own variant)
 }
-template <int I>
-static hipError_t launch_one ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
-    if ( p.lds_mode == 1 ) return launch_mode<I, 1> ( p, lds, stream );
-    if ( p.lds_mode == 2 ) return launch_mode<I, 2> ( p, lds, stream );
-    return launch_mode<I, 0> ( p, lds, stream );
+template <int MODE>
+static hipError_t launch_integrator ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
+    switch ( p.integrator ) {
+        case 0: return launch_mode<0, MODE> ( p, lds, stream );
+        case 1: return launch_mode<1, MODE> ( p, lds, stream );
+        case 2: return launch_mode<2, MODE> ( p, lds, stream );
+        case 3: return launch_mode<3, MODE> ( p, lds, stream );
+        case 4: return launch_mode<4, MODE> ( p, lds, stream );
+        case 5: return launch_mode<5, MODE> ( p, lds, stream );
+        case 6: return launch_mode<6, MODE> ( p, lds, stream );
+        default: return hipErrorInvalidValue;
+    }
 }
+// one launcher per template MODE, each in its own translation unit (see the top of the file)
+#if TERRA_TU_HAS ( 0 )
+hipError_t terra_launch_render_mode0 ( const DevRenderParams& p, size_t lds, hipStream_t stream ) { return launch_integrator<0> ( p, lds, stream ); }
+#endif
+#if TERRA_TU_HAS ( 1 )
+hipError_t terra_launch_render_mode1 ( const DevRenderParams& p, size_t lds, hipStream_t stream ) { return launch_integrator<1> ( p, lds, stream ); }
+#endif
+#if TERRA_TU_HAS ( 2 )
+hipError_t terra_launch_render_mode2 ( const DevRenderParams& p, size_t lds, hipStream_t stream ) { return launch_integrator<2> ( p, lds, stream ); }
+#endif
+#if TERRA_TU_HAS ( 3 )
+hipError_t terra_launch_render_mode3 ( const DevRenderParams& p, size_t lds, hipStream_t stream ) { return launch_integrator<3> ( p, lds, stream ); }
+#endif
 
+#if TERRA_TU_HAS ( 0 )
 // p.job_blocks and p.partials must be set (scene_host.cpp launch_render); p.job_queue (a zeroed word) = persistent grid fed by the queue, nullptr = plain launch
 bool terra_render_wants_queue ( const DevRenderParams& p ) {
 #ifdef TERRA_QUEUE_NEVER         // A/B builds: every loop launched plainly
@@ -780,16 +817,10 @@ hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream ) 
     if ( p.job_blocks == 0 ) return hipSuccess;
     if ( !p.partials ) return hipErrorInvalidValue;
     size_t lds = terra_lds_bytes ( p );
-    switch ( p.integrator ) {
-        case 0: return launch_one<0> ( p, lds, stream );
-        case 1: return launch_one<1> ( p, lds, stream );
-        case 2: return launch_one<2> ( p, lds, stream );
-        case 3: return launch_one<3> ( p, lds, stream );
-        case 4: return launch_one<4> ( p, lds, stream );
-        case 5: return launch_one<5> ( p, lds, stream );
-        case 6: return launch_one<6> ( p, lds, stream );
-        default: return hipErrorInvalidValue;
-    }
+    // DevRenderParams::lds_mode 2 = the fast tree; scenes outside the coordinate range of the containment proof (DevScene::reach) run the kernels that carry the replay
+    if ( p.lds_mode == 1 ) return terra_launch_render_mode1 ( p, lds, stream );
+    if ( p.lds_mode == 2 ) return p.scene.reach ? terra_launch_render_mode3 ( p, lds, stream ) : terra_launch_render_mode2 ( p, lds, stream );
+    return terra_launch_render_mode0 ( p, lds, stream );
 }
 
 uint32_t terra_render_blocks ( const DevRenderParams& p ) {
@@ -844,3 +875,4 @@ hipError_t terra_launch_tiles ( bool pack, float* pixels, void* results, uint32_
     else hipLaunchKernelGGL ( terra_tiles_kernel<false>, grid, dim3 ( 256 ), 0, stream, pixels, ( DevResult* ) results, fb_w, x, y, w, h, tile, rank, world, packed );
     return hipGetLastError();
 }
+#endif      // TERRA_TU_HAS ( 0 )

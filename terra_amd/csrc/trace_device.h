@@ -685,7 +685,8 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
     if ( cur != DEV_CHILD_EMPTY ) { TERRA_PUSH ( T, top, cur ); }      // leaving with a node in hand: it waits on the stack
 }
 
-template <int COUNT>
+// REACH = false: the kernels launched for scenes inside the coordinate range (template MODE 2) carry none of the replay code; MODE 3 = the same loops with it
+template <int COUNT, bool REACH = true>
 TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
     ClosestRanked best;
@@ -696,8 +697,8 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
         int* top = T.stack;
         *top = 0; top += TERRA_COL;
         bool traversing = true; uint32_t leaf = 0;
-        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, leaf, traversing, 0, c, pass == 1 );
-        if ( pass == 1 || !T.sc.reach || best.tri == 0xffffffffu || reference_reaches ( T, best.tri, r ) ) break;
+        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, leaf, traversing, 0, c, REACH && pass == 1 );
+        if ( !REACH || pass == 1 || !T.sc.reach || best.tri == 0xffffffffu || reference_reaches ( T, best.tri, r ) ) break;
     }
     return best;
 }
@@ -799,11 +800,11 @@ TD void surface_init ( const Tracer& T, uint32_t ti, V3 point, Surface& sf, uint
         t0 = lt[3 * ti]; t1 = lt[3 * ti + 1]; t2 = lt[3 * ti + 2];
         p0 = T.l_props[4 * ti]; p1 = T.l_props[4 * ti + 1]; p2 = T.l_props[4 * ti + 2]; p3x = T.l_props[4 * ti + 3];
     } else {
-        const float4* tris = reinterpret_cast<const float4*> ( MODE == 2 ? T.sc.fast_tris : T.sc.tris );
+        const float4* tris = reinterpret_cast<const float4*> ( MODE >= 2 ? T.sc.fast_tris : T.sc.tris );
         const float4* props = reinterpret_cast<const float4*> ( T.sc.props );
         t0 = tris[3 * ti]; t1 = tris[3 * ti + 1]; t2 = tris[3 * ti + 2];
         uint32_t pi = ti;
-        if ( MODE == 2 ) pi = T.sc.mats[__float_as_uint ( t0.w )].first_tri + __float_as_uint ( t1.w );
+        if ( MODE >= 2 ) pi = T.sc.mats[__float_as_uint ( t0.w )].first_tri + __float_as_uint ( t1.w );
         p0 = props[4 * pi]; p1 = props[4 * pi + 1]; p2 = props[4 * pi + 2]; p3x = props[4 * pi + 3];
     }
     V3 ta = v3 ( t0.x, t0.y, t0.z ), tb = v3 ( t1.x, t1.y, t1.z ), tc = v3 ( t2.x, t2.y, t2.z );
@@ -852,7 +853,7 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
     RayState st = ray_state_init ( r );
     if ( COUNT ) ++c.rays;
     Closest best;
-    if ( MODE == 2 ) { ClosestRanked b2 = bvh_traverse_fast<COUNT> ( T, r, st, c ); best.depth = b2.depth; best.tri = b2.tri; }
+    if ( MODE >= 2 ) { ClosestRanked b2 = bvh_traverse_fast<COUNT, MODE == 3> ( T, r, st, c ); best.depth = b2.depth; best.tri = b2.tri; }
     else best = bvh_traverse<COUNT, MODE> ( T, r, st, c );
     RaycastResult res; res.hit = best.tri != 0xffffffffu; res.tri = best.tri; res.object = 0; res.tri_in_object = 0;
     res.point = res.hit ? r.o + r.d * best.depth : v3 ( FLT_MAX, FLT_MAX, FLT_MAX );
@@ -860,7 +861,7 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
         uint32_t nattr;
         if ( pre ) *pre = path_draw<COUNT> ( T.sc.sincos24, *rb, c );
         surface_init<MODE, KINDS> ( T, best.tri, res.point, sf, res.object, res.tri_in_object, nattr );
-        if ( MODE == 2 ) res.tri = T.sc.mats[res.object].first_tri + res.tri_in_object;      // back to the soup index (lights, areas)
+        if ( MODE >= 2 ) res.tri = T.sc.mats[res.object].first_tri + res.tri_in_object;      // back to the soup index (lights, areas)
         if ( COUNT ) ++c.hits;
         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
     }
