@@ -18,7 +18,7 @@ scene replica, and ONE gather (RCCL over xGMI; terra_amd.runtime.gather_frame, t
 packed tiles to rank 0, which unpacks them into the full frame. Pack, gather and unpack run on a second stream: the next
 step's render (disjoint tiles) starts as soon as the pack has read the rank's own tiles. Total work is fixed as N grows:
 "scaling": "strong". value = frame samples * K / max-over-ranks wall time. Every rank count renders with the same sample split
-(terra_amd_set_sample_split, default 16 lanes per pixel: the frame of 16 successive 32-spp calls), so the image does not
+(terra_amd_set_sample_split, default 32 lanes per pixel: the frame of 32 successive 16-spp calls), so the image does not
 depend on N and a 1/8 share of the frame still fills a GPU.
 
 Also on the JSON line (rank 0):
@@ -58,9 +58,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (MI355X_MICROARCH.md "Execution model")
 TILE = 64
 # Sample split of the timed launches (terra_amd_set_sample_split): the frame equals that of this many successive calls of spp/split samples. With the job queue a
-# launch wants many jobs per resident lane -- at N = 8 a rank renders an eighth of the frame -- and 16 measures best at N = 1 too (Cornell 512 spp: split 8 / 16 / 32 / 64
-# -> 58.6 / 57.2 / 56.7 / 60.6 ms; slowest 1/8 share 9.04 / 8.44 / 8.34 / 8.25 ms; profiles/r03_measurements/shard_balance.log)
-DEFAULT_SPLIT = 16
+# launch wants many jobs per resident lane -- at N = 8 a rank renders an eighth of the frame -- and short jobs at its end (Cornell 512 spp: split 8 / 16 / 32 / 64
+# -> 58.6 / 57.2 / 56.7 / 60.6 ms, Direct 16 / 32 -> 112.0 / 108.9; slowest 1/8 share 9.04 / 8.44 / 8.34 / 8.25 ms; profiles/r03_measurements/shard_balance.log, ab_hall_split.log)
+DEFAULT_SPLIT = 32
 TREE_MODES = {"auto": 2, "reference": 0, "fast": 1}
 INTEGRATORS = {"simple": 0, "direct": 1, "mis": 2}
 

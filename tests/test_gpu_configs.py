@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 import bench  # noqa: E402  (nothing GPU-related at module level)
 
 TILE = 64       # bench.py's tile size
-SPLIT = bench.DEFAULT_SPLIT     # the sample split of bench.py's timed launches (16: the framebuffer of 16 successive calls of spp/16 samples)
+SPLIT = bench.DEFAULT_SPLIT     # the sample split of bench.py's timed launches (32: the framebuffer of 32 successive calls of spp/32 samples)
 THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 
 
