@@ -153,6 +153,8 @@ def workload(name: str, spp_override=0):
         d = scenes.cornell_phong(1920, 1080, 512, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "hall_1080p_256spp":        # BASELINE.json configs[2]: ~100k triangles, deep reference-tree traversal
         d = scenes.sponza_hall(1920, 1080, 256, bounces=8, integrator=api.kTerraIntegratorSimple)
+    elif name == "hall_1080p_64spp_direct":  # the same hall with the reference client's default integrator (satellite/include/Config.hpp), fewer samples to keep the run short
+        d = scenes.sponza_hall(1920, 1080, 64, bounces=8, integrator=api.kTerraIntegratorDirect)
     elif name == "hall_2160p_4096spp":       # BASELINE.json configs[4]: the 100k scene at 3840x2160, 4096 spp (meant for 8 GPUs)
         d = scenes.sponza_hall(3840, 2160, 4096, bounces=8, integrator=api.kTerraIntegratorSimple)
     elif name == "hall_x100_1080p_64spp":    # the hall with every coordinate (scene and camera) x 100: outside the +-13-unit range of the containment proof, the
@@ -589,6 +591,7 @@ EXTRA_WORKLOADS = [
     ("hall_x100_1080p_64spp", "auto", "simple", 4, 2, 1, None, 6.0),                   # the hall outside the coordinate range: fast tree + reachability replay
     ("spheres_1080p_1024spp", "auto", "simple", DEFAULT_SPLIT, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
     ("cornell_1080p_512spp_direct", "auto", "direct", DEFAULT_SPLIT, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
+    ("hall_1080p_64spp_direct", "auto", "direct", 8, 2, 1, None, 6.0),                             # configs[2]'s scene with that integrator (64 spp)
 ]
 
 

@@ -33,6 +33,7 @@ CONFIGS = [
     ("hall_1080p_256spp", "reference", "simple", bench.DEFAULT_SPLIT, ["--steps", "1", "--warmup", "0"]),
     ("spheres_1080p_1024spp", "auto", "simple", bench.DEFAULT_SPLIT, ["--steps", "1", "--warmup", "1"]),
     ("hall_x100_1080p_64spp", "auto", "simple", 4, ["--steps", "2", "--warmup", "1"]),
+    ("hall_1080p_64spp_direct", "auto", "direct", 8, ["--steps", "2", "--warmup", "1"]),
 ]
 PASSES = {
     "sq1": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU"],
