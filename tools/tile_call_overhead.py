@@ -1,3 +1,6 @@
+"""What one terra_render() call on a tile costs from a single thread (dev tool, GPU box): at 1 spp the kernel is negligible, so the time is the
+call's fixed cost (upload of the running sums, launch, resolve, two downloads, the wait); at 512 spp the tile's own render is added.
+    python3 tools/tile_call_overhead.py"""
 import torch, ctypes as C, sys, time, os
 sys.path.insert(0, os.getcwd())
 from terra_amd import api, runtime, scenes
