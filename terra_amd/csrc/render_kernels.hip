@@ -27,6 +27,9 @@
 //   TERRA_TU 0  everything that is not a render-kernel instance (resolve / tile kernels, LDS planning, the launch dispatch) + the kernels of template MODE 0
 //   TERRA_TU 1 / 2 / 3  the kernels of template MODE 1 (LDS-resident scenes) / 2 (fast tree) / 3 (fast tree + reachability replay) and their launcher
 //   undefined   all of it in one unit (tools/kernel_resources.sh, tools/isa_cost.py)
+#ifndef TERRA_JOB_STREAM_TABLE      // the jobs' random streams keyed by a kernel of their own ahead of the render (DevRenderParams::job_streams): 0 = by the lane that takes the job
+#define TERRA_JOB_STREAM_TABLE 1
+#endif
 #ifdef TERRA_TU
 #define TERRA_TU_HAS(k) ( TERRA_TU == ( k ) )
 #else
@@ -373,7 +376,9 @@ TD void job_init_lane ( const DevRenderParams& p, float* aux ) {
 // Job boundary, for whichever lanes of the wave call it together: store the finished job's sum, take the next job from the wave's pool (claiming a new batch from
 // the queue when it runs dry), set up its pixel and streams. Leaves j.s == chunk_spp when the job is a pixel outside the rectangle (the job space is made of whole
 // 16x16 blocks): the lane simply asks again. Only the calling lanes' registers change; the pool lives in LDS because the lanes that are not here must see it move too.
-template <int COUNT>
+// TABLE: the job's streams come keyed from DevRenderParams::job_streams (LDS-resident scenes, whose kernels are bound by instruction issue: Cornell 56.7 -> 55.1 ms; the
+// kernels that wait on memory lose a little to the table's 64 bytes of traffic per job -- hall 244.1 -> 245.7 ms -- and key their streams here)
+template <int COUNT, bool TABLE>
 TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& rs, const Counters& c ) {
     uint32_t* auxu = reinterpret_cast<uint32_t*> ( aux );
     const uint32_t fin = auxu[768];
@@ -406,8 +411,17 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
     if ( !got ) { j.exhausted = true; return; }                  // the queue is monotone: a batch that does not cover the askers means nothing is left, ever
     uint32_t chunk;
     if ( !job_pixel ( p, job, j.px, j.py, chunk ) ) return;
-    const int prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( j.py - p.st_y ) * p.st_pitch + ( j.px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
-    rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) j.py * p.fb_w + j.px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
+    int prior_samples;
+    if constexpr ( TERRA_JOB_STREAM_TABLE && TABLE ) {
+        const uint4 e0 = p.job_streams[2 * ( size_t ) job], e1 = p.job_streams[2 * ( size_t ) job + 1];       // keyed by terra_job_streams_kernel (below)
+        rs.a.state = ( uint64_t ) e0.x | ( ( uint64_t ) e0.y << 32 ); rs.a.inc = 1;
+        rs.b.state = ( uint64_t ) e0.z | ( ( uint64_t ) e0.w << 32 ); rs.b.inc = ( uint64_t ) e1.x | ( ( uint64_t ) e1.y << 32 );
+        rs.seedA = e1.z;
+        prior_samples = ( int ) e1.w;
+    } else {
+        prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( j.py - p.st_y ) * p.st_pitch + ( j.px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
+        rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) j.py * p.fb_w + j.px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
+    }
     aux[0] = 0.f; aux[256] = 0.f; aux[512] = 0.f; auxu[768] = job;
     if ( COUNT == 2 ) auxu[1024] = c.rand_calls;
     j.s = 0; j.base = ( uint32_t ) prior_samples + chunk * p.chunk_spp;
@@ -481,7 +495,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     }
                 }
                 if ( !start ) {
-                    if ( jb.s == p.chunk_spp ) { job_next<COUNT> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
+                    if ( jb.s == p.chunk_spp ) { job_next<COUNT, MODE == 1> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
                     if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                         ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
@@ -533,7 +547,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     }
                 }
                 if ( !start ) {                                  // the path ended (or none was started yet): the pixel's next sample, or the lane's next job
-                    if ( jb.s == p.chunk_spp ) { job_next<COUNT> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
+                    if ( jb.s == p.chunk_spp ) { job_next<COUNT, MODE == 1> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
                     if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                         ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
@@ -574,7 +588,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     if ( !next ) { deposit ( acc_lds, Lo ); have_ray = false; }
                 }
                 if ( !next ) {
-                    if ( jb.s == p.chunk_spp ) { job_next<COUNT> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
+                    if ( jb.s == p.chunk_spp ) { job_next<COUNT, MODE == 1> ( p, acc_lds, jb, rs, c ); if ( jb.exhausted ) done = true; }
                     if ( jb.s != p.chunk_spp ) {
                         float r1 = trng_a_float ( rs.a ), r2 = trng_a_float ( rs.a );
                         ro = cam_pos; rd = camera_sample ( p, jb.px, jb.py, r1, r2 );
@@ -609,7 +623,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         const bool any_alive = __any ( alive );
         if ( !alive ) {
             // (a lane waits at the boundary until TERRA_JOB_FETCH_MIN lanes do, or nobody is tracing: the switch then serves several lanes per execution)
-            if ( jb.s == p.chunk_spp && ( TERRA_JOB_FETCH_MIN <= 1 || !any_alive || __popcll ( __ballot ( jb.s == p.chunk_spp ) ) >= TERRA_JOB_FETCH_MIN ) ) job_next<COUNT> ( p, acc_lds, jb, rs, c );
+            if ( jb.s == p.chunk_spp && ( TERRA_JOB_FETCH_MIN <= 1 || !any_alive || __popcll ( __ballot ( jb.s == p.chunk_spp ) ) >= TERRA_JOB_FETCH_MIN ) ) job_next<COUNT, MODE == 1> ( p, acc_lds, jb, rs, c );
             if ( jb.exhausted ) break;
             if ( jb.s != p.chunk_spp ) {
                 PS_WAVE ( c, kPsCamIter ); PS_LANE ( c, kPsCamLanes );
@@ -827,6 +841,24 @@ uint32_t terra_render_blocks ( const DevRenderParams& p ) {
     uint32_t bpt = p.tile_size / 16;
     return own_tiles ( p.w, p.h, p.tile_size, p.rank, p.world ) * bpt * bpt;
 }
+// First kernel of every render: the random streams of every job of the launch (what job_next would otherwise compute when a lane takes the job). One thread per job,
+// numbered like the render kernel's jobs; a job whose pixel lies outside the rectangle has no entry (nobody reads it).
+__global__ __launch_bounds__ ( 256 ) void terra_job_streams_kernel ( DevRenderParams p ) {
+    const uint32_t job = blockIdx.x * 256u + threadIdx.x;
+    uint32_t px, py, chunk;
+    if ( !job_pixel ( p, job, px, py, chunk ) ) return;
+    const int prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
+    const PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
+    p.job_streams[2 * ( size_t ) job] = make_uint4 ( ( uint32_t ) rs.a.state, ( uint32_t ) ( rs.a.state >> 32 ), ( uint32_t ) rs.b.state, ( uint32_t ) ( rs.b.state >> 32 ) );
+    p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( ( uint32_t ) rs.b.inc, ( uint32_t ) ( rs.b.inc >> 32 ), rs.seedA, ( uint32_t ) prior_samples );
+}
+hipError_t terra_launch_job_streams ( const DevRenderParams& p, hipStream_t stream ) {
+    if ( terra_job_streams_bytes ( p ) == 0 ) return hipSuccess;
+    if ( !p.job_streams ) return hipErrorInvalidValue;
+    hipLaunchKernelGGL ( terra_job_streams_kernel, dim3 ( p.job_blocks ), dim3 ( 256 ), 0, stream, p );
+    return hipGetLastError();
+}
+size_t terra_job_streams_bytes ( const DevRenderParams& p ) { return ( TERRA_JOB_STREAM_TABLE && p.lds_mode == 1 ) ? ( size_t ) p.job_blocks * 256 * 32 : 0; }      // (p.job_blocks set)
 hipError_t terra_launch_resolve ( const DevRenderParams& p, hipStream_t stream ) {
     uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return hipSuccess;

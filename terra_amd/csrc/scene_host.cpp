@@ -1138,7 +1138,10 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
         pool_device = s->device;
     }
     const size_t header = 256;                                     // the job queue word (+ padding that keeps the partials 256-byte aligned)
-    const size_t scratch_bytes = header + ( size_t ) split * blocks * 256 * sizeof ( float4 );
+    const size_t partial_bytes = ( size_t ) split * blocks * 256 * sizeof ( float4 );
+    p.job_blocks = blocks * split;
+    const size_t stream_bytes = terra_job_streams_bytes ( p );
+    const size_t scratch_bytes = header + partial_bytes + stream_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)]
     void* scratch = slot ? slot_scratch ( slot, scratch_bytes ) : nullptr;
     const bool pooled = scratch == nullptr;
     if ( pooled ) HIP_TRY ( hipMallocAsync ( &scratch, scratch_bytes, stream ), kTerraAmdErrNoDevice );
@@ -1148,6 +1151,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     p.split = split; p.split_log2 = 0; while ( ( 1u << p.split_log2 ) < split ) ++p.split_log2;
     p.chunk_spp = p.spp / split; p.partials = ( float4* ) ( ( char* ) scratch + header );
     p.job_blocks = blocks * split; p.job_queue = terra_render_wants_queue ( p ) ? ( uint32_t* ) scratch : nullptr;
+    p.job_streams = stream_bytes ? ( uint4* ) ( ( char* ) scratch + header + partial_bytes ) : nullptr;
     {   // the job decode divides block numbers by launch constants: as multiplications by ceil(2^32 / d), exact while (largest dividend) * divisor < 2^32
         const uint64_t bpt = p.tile_size / 16, bpt2 = bpt * bpt, tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size, tiles_y = ( p.h + p.tile_size - 1 ) / p.tile_size;
         auto magic = [] ( uint64_t d ) { return d <= 1 ? 0u : ( uint32_t ) ( ( ( 1ull << 32 ) + d - 1 ) / d ); };
@@ -1157,6 +1161,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
         }
         p.job_div_bpt2 = magic ( bpt2 ); p.job_div_tiles_x = magic ( tiles_x ); p.job_div_bpt = magic ( bpt ); p.job_tiles_x = ( uint32_t ) tiles_x;
     }
+    if ( e == hipSuccess ) e = terra_launch_job_streams ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_render ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_resolve ( p, stream );
     if ( pooled ) ( void ) hipFreeAsync ( scratch, stream );

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 hipError_t terra_launch_render ( const DevRenderParams&, hipStream_t ) { return hipErrorNoDevice; }
+hipError_t terra_launch_job_streams ( const DevRenderParams&, hipStream_t ) { return hipErrorNoDevice; }
+size_t terra_job_streams_bytes ( const DevRenderParams& ) { return 0; }
 hipError_t terra_fill_sincos24 ( float2*, hipStream_t ) { return hipErrorNoDevice; }
 bool       terra_render_wants_queue ( const DevRenderParams& ) { return false; }
 uint32_t   terra_render_blocks ( const DevRenderParams& ) { return 0; }
