@@ -173,7 +173,7 @@ struct DevRenderParams {
     uint32_t split, split_log2, chunk_spp;
     float4*  partials;
     // job_streams[2 * job], [2 * job + 1]: the random streams of job `job`, keyed ahead of the render kernel by terra_job_streams_kernel with every lane busy -- {A.state, B.state},
-    // {B.inc, seedA, samples already in the pixel} -- so that a lane at a job boundary loads 32 bytes instead of hashing its keys (ten 64-bit multiplications) nearly alone
+    // {B.inc, px | py << 16 (all ones: a pixel outside the rectangle), samples already in the pixel} -- so that a lane at a job boundary loads 32 bytes instead of hashing its keys (ten 64-bit multiplications) nearly alone
     uint4*   job_streams;
     // job space of the persistent render grid (render_kernels.hip "jobs"): job_blocks virtual 256-thread blocks = (16x16 pixel blocks of the
     // shard) * split; *job_queue (zeroed before the launch) hands out the jobs beyond the ones the launched lanes start with

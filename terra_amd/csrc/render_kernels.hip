@@ -410,15 +410,19 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
     if ( ahead == 0 ) { pool[0] = next; pool[1] = end; }
     if ( !got ) { j.exhausted = true; return; }                  // the queue is monotone: a batch that does not cover the askers means nothing is left, ever
     uint32_t chunk;
-    if ( !job_pixel ( p, job, j.px, j.py, chunk ) ) return;
     int prior_samples;
     if constexpr ( TERRA_JOB_STREAM_TABLE && TABLE ) {
-        const uint4 e0 = p.job_streams[2 * ( size_t ) job], e1 = p.job_streams[2 * ( size_t ) job + 1];       // keyed by terra_job_streams_kernel (below)
+        const uint4 e1 = p.job_streams[2 * ( size_t ) job + 1];       // keyed by terra_job_streams_kernel (below): the job's pixel comes with it, the decode's divisions are not repeated here
+        if ( e1.z == 0xffffffffu ) return;                                 // (a pixel outside the rectangle)
+        const uint4 e0 = p.job_streams[2 * ( size_t ) job];
+        j.px = e1.z & 0xffffu; j.py = e1.z >> 16;
+        chunk = ( job >> 8 ) & ( p.split - 1 );
         rs.a.state = ( uint64_t ) e0.x | ( ( uint64_t ) e0.y << 32 ); rs.a.inc = 1;
         rs.b.state = ( uint64_t ) e0.z | ( ( uint64_t ) e0.w << 32 ); rs.b.inc = ( uint64_t ) e1.x | ( ( uint64_t ) e1.y << 32 );
-        rs.seedA = e1.z;
+        rs.seedA = 0;                                                      // (only trng_pixel_streams itself uses it)
         prior_samples = ( int ) e1.w;
     } else {
+        if ( !job_pixel ( p, job, j.px, j.py, chunk ) ) return;
         prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( j.py - p.st_y ) * p.st_pitch + ( j.px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
         rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) j.py * p.fb_w + j.px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     }
@@ -846,11 +850,11 @@ uint32_t terra_render_blocks ( const DevRenderParams& p ) {
 __global__ __launch_bounds__ ( 256 ) void terra_job_streams_kernel ( DevRenderParams p ) {
     const uint32_t job = blockIdx.x * 256u + threadIdx.x;
     uint32_t px, py, chunk;
-    if ( !job_pixel ( p, job, px, py, chunk ) ) return;
+    if ( !job_pixel ( p, job, px, py, chunk ) ) { p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( 0u, 0u, 0xffffffffu, 0u ); return; }
     const int prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
     const PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     p.job_streams[2 * ( size_t ) job] = make_uint4 ( ( uint32_t ) rs.a.state, ( uint32_t ) ( rs.a.state >> 32 ), ( uint32_t ) rs.b.state, ( uint32_t ) ( rs.b.state >> 32 ) );
-    p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( ( uint32_t ) rs.b.inc, ( uint32_t ) ( rs.b.inc >> 32 ), rs.seedA, ( uint32_t ) prior_samples );
+    p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( ( uint32_t ) rs.b.inc, ( uint32_t ) ( rs.b.inc >> 32 ), px | ( py << 16 ), ( uint32_t ) prior_samples );      // (frames of up to 65,535 x 65,535: scene_host.cpp launch_render refuses larger ones)
 }
 hipError_t terra_launch_job_streams ( const DevRenderParams& p, hipStream_t stream ) {
     if ( terra_job_streams_bytes ( p ) == 0 ) return hipSuccess;

@@ -1141,6 +1141,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     const size_t partial_bytes = ( size_t ) split * blocks * 256 * sizeof ( float4 );
     p.job_blocks = blocks * split;
     const size_t stream_bytes = terra_job_streams_bytes ( p );
+    if ( stream_bytes && ( p.fb_w > 65535u || p.fb_h > 65535u ) ) return fail ( kTerraAmdErrBadArgument, "framebuffer of %u x %u: at most 65,535 pixels per side (the job table packs a pixel into 32 bits)", p.fb_w, p.fb_h );
     const size_t scratch_bytes = header + partial_bytes + stream_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)]
     void* scratch = slot ? slot_scratch ( slot, scratch_bytes ) : nullptr;
     const bool pooled = scratch == nullptr;
