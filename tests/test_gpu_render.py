@@ -662,6 +662,15 @@ def test_ragged_frames_and_tiles(H, L, orc_lib, devmath_mode):
     scene = scenes.build_scene(L, d); cam = scenes.camera_of(d); fb = runtime.DeviceFramebuffer(70, 50)
     assert L.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), 70, 50, 60, 0, 11, 5, None, None) < 0
     assert L.render_device(C.byref(cam), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), 70, 50, 0, 0, 0, 5, None, None) < 0
+    # the job table of LDS-resident launches packs a pixel into 32 bits: a frame with a side above 65,535 is refused with a message, a side of 65,535 renders
+    wide = runtime.DeviceFramebuffer(65536, 1)
+    L.clear_error()
+    assert L.render_device(C.byref(cam), scene, wide.pixels.data_ptr(), wide.results.data_ptr(), 65536, 1, 65000, 0, 536, 1, None, None) < 0 and "65,535" in runtime.last_error()
+    L.clear_error()
+    ok = runtime.DeviceFramebuffer(65535, 1)
+    assert L.render_device(C.byref(cam), scene, ok.pixels.data_ptr(), ok.results.data_ptr(), 65535, 1, 65000, 0, 535, 1, None, None) == 0
+    import torch; torch.cuda.synchronize()
+    assert (ok.results_host()["samples"][0, 65000:] == 2).all()
     L.scene_destroy(scene)
 
 
