@@ -116,8 +116,8 @@ int  terra_amd_debug_shrink_reference_boxes ( HTerraScene scene, float amount );
    (each call of the reference sums its own samples and then adds them to the running sum,
    src/Terra.c:551-572). It exists for small tiles and shards: one GPU has more lanes than a 1/8 share
    of a 1080p frame has pixels. If spp is not a multiple of S the largest power of two dividing it is
-   used. split = 0 picks S per call from the call's own size (about 48 jobs per lane the
-   GPU holds at once, chunks of at least 16 samples, at most 32 lanes per pixel: 8 for a 1080p frame of >= 128 spp, 32 for a 128-pixel tile at 512 spp): for clients that
+   used. split = 0 picks S per call from the call's own size (about 200 jobs per lane the
+   GPU holds at once, chunks of at least 16 samples, at most 32 lanes per pixel: 32 for a 1080p frame or a 128-pixel tile at 512 spp, 8 at 128 spp): for clients that
    render in small tiles, as the reference's does (satellite/include/Config.hpp:25), and for whole frames alike -- the render grid
    is persistent and hands (pixel, chunk) jobs to its lanes from a queue, and a launch with few jobs per lane ends with its last jobs
    ramping down alone. A launch parameter: no commit needed. */

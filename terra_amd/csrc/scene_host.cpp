@@ -1122,12 +1122,13 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     const uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return 0;
     if ( split == 0 ) {
-        // automatic: about 48 jobs per lane the GPU holds at once (256 CUs x 5 blocks x 256 lanes), chunks of at least 16 samples. A launch whose lanes get only
+        // automatic: about 200 jobs per lane the GPU holds at once (256 CUs x 5 blocks x 256 lanes), chunks of at least 16 samples, at most 32 lanes per pixel (Cornell 1080p
+        // 512 spp: 8 / 16 / 32 / 64 lanes per pixel -> 57.5 / 55.8 / 55.1 / 59.8 ms; profiles/r03_measurements/ab_job_queue.log). A launch whose lanes get only
         // a handful of jobs each ends with its last jobs ramping down alone (hall 1080p 256 spp: split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms); a small tile wants
         // the split to fill the GPU at all. Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
         split = 1;
         // (up to 32 lanes per pixel: the reference client's 128-pixel tiles at 512 spp, called from 8 threads, 69.1 -> 66.7 ms per frame with 32 instead of 16)
-        while ( split < 32 && ( uint64_t ) blocks * split < 61440 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
+        while ( split < 32 && ( uint64_t ) blocks * split < 245760 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
     }
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
     if ( split < 1 ) split = 1;
