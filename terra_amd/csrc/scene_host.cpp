@@ -1144,7 +1144,8 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     const size_t stream_bytes = terra_job_streams_bytes ( p );
     if ( stream_bytes && ( p.fb_w > 65535u || p.fb_h > 65535u ) ) return fail ( kTerraAmdErrBadArgument, "framebuffer of %u x %u: at most 65,535 pixels per side (the job table packs a pixel into 32 bits)", p.fb_w, p.fb_h );
     const size_t scratch_bytes = header + partial_bytes + stream_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)]
-    void* scratch = slot ? slot_scratch ( slot, scratch_bytes ) : nullptr;
+    // (a thread's slot keeps scratch for tile-sized calls only: a full-frame call's gigabytes come from, and go back to, the device's pool)
+    void* scratch = ( slot && scratch_bytes <= ( size_t ( 256 ) << 20 ) ) ? slot_scratch ( slot, scratch_bytes ) : nullptr;
     const bool pooled = scratch == nullptr;
     if ( pooled ) HIP_TRY ( hipMallocAsync ( &scratch, scratch_bytes, stream ), kTerraAmdErrNoDevice );
     // the queue word must be zero when the render kernel starts: a slot's scratch is zeroed when it is allocated and again by every resolve kernel (one kernel less per
