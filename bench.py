@@ -81,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--sample-split", type=int, default=DEFAULT_SPLIT, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
     ap.add_argument("--check", action="store_true", help="after timing: one low-spp sharded+gathered pass into a fresh frame must equal an unsharded pass bit for bit (rank 0); on by default when N > 1")
     ap.add_argument("--no-check", action="store_true", help="N > 1: skip that extra pass")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-started N-rank child may run before it is killed (a hung rendezvous must not hang the parent)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started N-rank child may run before its process group is killed (a hung rendezvous must not hang the parent; well below the driver's own 1500 s limit, so that the ranks are gone before the driver kills this parent)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0 = pick a free one)")
     return ap.parse_args(argv)
 
@@ -102,23 +102,46 @@ def free_port():
         return s.getsockname()[1]
 
 
+def _die_with_parent():
+    """preexec of the launcher child: SIGKILL when this process dies without having stopped it (the handlers below cannot run on SIGKILL)"""
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, 9, 0, 0, 0)          # PR_SET_PDEATHSIG, SIGKILL
+    except OSError:
+        pass
+
+
 def self_launch(args, argv) -> int:
-    """bench.py --gpus N (N > 1) without a launcher: run the N ranks as a child torch.distributed.run (its own process group, so a hung
-    rendezvous can be killed whole after --launch-timeout), pass the ranks' stderr through live, relay rank 0's JSON line"""
+    """bench.py --gpus N (N > 1) without a launcher: run the N ranks as a child torch.distributed.run in its own process group, so that the WHOLE group can be
+    killed -- after --launch-timeout (a hung rendezvous), or when this parent is told to stop: SIGTERM / SIGINT / SIGHUP aimed at the parent are forwarded as a
+    SIGKILL of the group (the ranks live in another session and would otherwise keep the GPUs) -- pass the ranks' stderr through live, relay rank 0's JSON line"""
     import signal
     port = args.master_port or free_port()
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.Popen(launcher_command(args, argv, port), env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
-    try:
-        stdout, _ = p.communicate(timeout=args.launch_timeout)
-    except subprocess.TimeoutExpired:
+    p = subprocess.Popen(launcher_command(args, argv, port), env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True, preexec_fn=_die_with_parent)
+
+    def kill_group():
         try:
             os.killpg(p.pid, signal.SIGKILL)            # the exact group this call started
         except ProcessLookupError:
             pass
-        stdout, _ = p.communicate()
-        sys.stderr.write((stdout or "")[-4000:] + f"\nbench.py: the {args.gpus}-rank child did not finish within {args.launch_timeout:.0f} s and was killed\n")
-        return 124
+
+    def on_signal(signum, _frame):
+        kill_group()
+        sys.stderr.write(f"bench.py: signal {signum}: the {args.gpus}-rank child's process group was killed\n")
+        os._exit(128 + signum)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    try:
+        try:
+            stdout, _ = p.communicate(timeout=args.launch_timeout)
+        except subprocess.TimeoutExpired:
+            kill_group()
+            stdout, _ = p.communicate()
+            sys.stderr.write((stdout or "")[-4000:] + f"\nbench.py: the {args.gpus}-rank child did not finish within {args.launch_timeout:.0f} s and was killed\n")
+            return 124
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
     line = None
     for ln in (stdout or "").splitlines():
         if ln.startswith("{") and '"metric"' in ln:

@@ -606,6 +606,12 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 #ifndef TERRA_FAST_LEAF_16THS
 #define TERRA_FAST_LEAF_16THS 8
 #endif
+#ifndef TERRA_PROBE_VMEM
+#define TERRA_PROBE_VMEM 0
+#endif
+#ifndef TERRA_PROBE_VALU
+#define TERRA_PROBE_VALU 0
+#endif
 #ifndef TERRA_FAST_PREFIX_MODE     // how a node of the fast tree is fetched: 1 = one flat load from the staged prefix (LDS) or global memory; 0 / 2: A/B forms below
 #define TERRA_FAST_PREFIX_MODE 1
 #endif
@@ -652,12 +658,24 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
+#if TERRA_PROBE_VMEM          // (sensitivity probe, measurement builds only) one more 16-byte request per node step: 1 = the neighbouring node (same 128-B line), 2 = a node far away
+                    { const uint32_t w2 = TERRA_PROBE_VMEM == 1 ? ( w ^ 1u ) : ( w * 7919u + 13u ) % T.sc.n_fast_nodes; const float4 x = nodes[4 * ( size_t ) w2]; asm volatile ( "" :: "v" ( x.x ) ); }
+#endif
+#if TERRA_PROBE_VALU          // (sensitivity probe) this many extra dependent v_fma_f32 per node step
+                    { float dummy = q0.x;
+                      #pragma unroll
+                      for ( int k = 0; k < TERRA_PROBE_VALU; ++k ) asm volatile ( "v_fma_f32 %0, %0, %0, %0" : "+v" ( dummy ) );
+                      asm volatile ( "" :: "v" ( dummy ) ); }
+#endif
                     float te0, te1;
                     bool hit0 = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te0 ) && te0 <= best.depth && child0 != DEV_CHILD_EMPTY;
                     bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;
                     if ( hit0 && hit1 ) {
                         bool zero_near = te0 <= te1;
                         TERRA_PUSH ( T, top, ( zero_near ? child1 : child0 ) );
+#if TERRA_PHASE_STATS
+                        { const int dpt = ( int ) ( top - T.stack ) / TERRA_COL; ++c.ps[kPsCamLanes]; c.ps[kPsShadeIter] += dpt >= 4; c.ps[kPsRayLanes] += dpt >= 6; c.ps[kPsCamIter] += dpt >= 8; c.ps[kPsDrainIter] += dpt >= 10; c.ps[kPsShadeLanes] += dpt >= 12; }
+#endif
                         cur = zero_near ? child0 : child1;
                     } else if ( hit0 ) cur = child0;
                     else if ( hit1 ) cur = child1;

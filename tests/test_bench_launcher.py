@@ -56,6 +56,46 @@ def test_self_launch_kills_a_hung_child_after_the_timeout(monkeypatch, capfd, tm
     assert rc == 124 and dt < 20 and "did not finish within" in io.err and io.out == ""
 
 
+def test_a_signal_aimed_at_the_parent_takes_the_rank_group_down(tmp_path):
+    """the ranks live in their own session: SIGTERM (what a driver's timeout sends) to the bench.py parent must kill their whole process group, or they would
+    outlive it holding the GPUs; and if the parent is SIGKILLed, PR_SET_PDEATHSIG takes the launcher child down"""
+    import os, signal, time
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        pidfile = tmp_path / f"pid{int(sig)}"
+        child = tmp_path / "child.py"
+        child.write_text(f"import os, time, subprocess, sys\nsub = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\nopen({str(pidfile)!r}, 'w').write(f'{{os.getpid()}} {{sub.pid}}')\ntime.sleep(600)\n")
+        parent = tmp_path / "parent.py"
+        parent.write_text(f"import sys\nsys.path.insert(0, {str(ROOT)!r})\nimport bench\nbench.launcher_command = lambda args, argv, port: [sys.executable, {str(child)!r}]\n"
+                          "args = bench.parse_args(['--gpus', '2'])\nsys.exit(bench.self_launch(args, ['--gpus', '2']))\n")
+        p = subprocess.Popen([sys.executable, str(parent)], stderr=subprocess.PIPE, text=True)
+        for _ in range(200):
+            if pidfile.exists() and len(pidfile.read_text().split()) == 2:
+                break
+            time.sleep(0.05)
+        launcher, grandchild = map(int, pidfile.read_text().split())
+        p.send_signal(sig)
+        p.wait(timeout=20)
+        if sig == signal.SIGTERM:
+            assert p.returncode == 128 + signal.SIGTERM and "process group was killed" in p.stderr.read()
+
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                return False
+            try:          # (a zombie still answers signal 0)
+                return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+            except OSError:
+                return False
+        deadline = time.time() + 10
+        pids = (launcher, grandchild) if sig == signal.SIGTERM else (launcher,)          # (SIGKILL of the parent: the launcher dies by PDEATHSIG; its own children are torchrun's business)
+        while time.time() < deadline and any(alive(q) for q in pids):
+            time.sleep(0.05)
+        assert not any(alive(q) for q in pids)
+        if sig == signal.SIGKILL and alive(grandchild):
+            os.kill(grandchild, signal.SIGKILL)          # the exact PID this test started
+
+
 def test_bare_invocation_with_gpus_gt_1_never_touches_the_gpu_in_the_parent(tmp_path):
     """the parent must not import torch / the library before it has spawned the ranks: here (no GPU) the child fails, and the
     parent reports that failure instead of dying on its own GPU check"""

@@ -5,8 +5,8 @@ a crop of the finished frame against the oracle (bit-exact: sums, tonemapped pix
 where the launch reports them), and size-independent properties of the whole frame (sample counts, determinism of the
 shard -> pack -> unpack path, counter identities).
 
-  configs[1]  Cornell box 1920x1080, 512 spp, 8 bounces -- the exact bench.py launch: sample split 8, i.e. the
-              framebuffer of 8 successive calls of 64 spp (reference src/Terra.c:551-572: a call sums its samples from
+  configs[1]  Cornell box 1920x1080, 512 spp, 8 bounces -- the exact bench.py launch: its sample split (bench.DEFAULT_SPLIT = 32), i.e. the
+              framebuffer of 32 successive calls of 16 spp (reference src/Terra.c:551-572: a call sums its samples from
               zero, adds them to the running sum and re-tonemaps)
   configs[2]  ~100k-triangle hall 1920x1080, 256 spp: automatic (what bench.py times), replica and forced fast tree;
               plus the hall x 100 (outside the containment range: reachability mode) at bench.py's 1080p / 64 spp
@@ -88,8 +88,8 @@ def device_frame(L, d, split=1, tree_mode=None, calls=True, shard=None, counters
     return out
 
 
-def test_config2_headline_launch_cornell_1080p_512spp_split8(H, L, orc_lib, devmath_mode):
-    """the launch bench.py times: 1920x1080, 512 spp, its sample split (16: == 16 reference calls of 32 spp), library defaults"""
+def test_config2_headline_launch_cornell_1080p_512spp_bench_split(H, L, orc_lib, devmath_mode):
+    """the launch bench.py times: 1920x1080, 512 spp, its sample split (bench.DEFAULT_SPLIT = 32: == 32 reference calls of 16 spp), library defaults"""
     d = scenes.cornell_box(1920, 1080, 512, bounces=8)
     got = device_frame(L, d, split=SPLIT, calls=False, counters=False)      # exactly bench.py's timed launch: library defaults -- automatic traversal, no work counters -- and its sample split
     assert got["tree_mode"] == 2 and got["traversal"] == "reference tree + leaf-box cull"      # what BENCH's config.traversal names

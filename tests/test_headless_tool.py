@@ -135,13 +135,16 @@ def test_tool_quads_relative_indices_and_missing_files(H, ref_lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_tool_against_the_product(H, amd_lib, tmp_path):
+def test_tool_against_the_product(H, amd_lib, orc_lib, devmath_mode, tmp_path):
+    """OBJ/MTL -> tool (linked against libterra_amd.so) -> PFM == the ORACLE's render of the same scene description, bit for bit (device-twin math: the parity
+    leg of SURVEY 8f N1 on the GPU; reference caller satellite/src/Scene.cpp:133-245), for both tree modes -- and == a direct API render through the product"""
     from terra_amd import runtime
     from test_gpu_render import render_host
     L = runtime.load()
     exe = build_tool(H, tmp_path, "amd")
     d = scenes.cornell_phong(96, 64, 4, integrator=api.kTerraIntegratorDirect, jitter=0.5, tonemap=api.kTerraTonemappingOperatorReinhard, environment=(0.4, 0.52, 1.0))
-    want = render_host(L, d)["pixels"]
+    want = H.Unit("orc").render_pixels(d, want_calls=False)["pixels"]          # the checker: the oracle, not the product
+    assert np.array_equal(render_host(L, d)["pixels"].view(np.uint32), want.view(np.uint32))
     obj = tmp_path / "cornell.obj"
     write_obj(d, obj, mirror_z=True)
     out = tmp_path / "direct.pfm"

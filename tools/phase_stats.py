@@ -45,6 +45,10 @@ def main():
         if v[it]:
             print(f"{ph:6s} wave execs {v[it]:14d}  lanes {v[ln]:16d}  utilisation {v[ln] / (64.0 * v[it]):.3f}   per ray-iter {v[it] / max(1, v['ray_iter']):.2f}")
     print(f"drains per ray-iter {v['drain_iter'] / max(1, v['ray_iter']):.3f}")
+    if v["top4096"] and v["cam_lanes"] and not v["ray_iter"]:      # fast-tree launches (decoupled loop): the slots of the coupled loop hold the stack-depth histogram of the pushes
+        n = v["cam_lanes"]
+        print(f"fast tree stack: {n} pushes ({n / max(1, st['rays']):.2f} per ray); entries on the lane's stack after the push >= 4: {100.0 * v['shade_iter'] / n:.2f} %, >= 6: {100.0 * v['ray_lanes'] / n:.2f} %, "
+              f">= 8: {100.0 * v['cam_iter'] / n:.3f} %, >= 10: {100.0 * v['drain_iter'] / n:.4f} %, >= 12: {100.0 * v['shade_lanes'] / n:.5f} %")
     if v["top4096"]:
         print("node visits served by a breadth-first prefix of the node array: " + ", ".join(f"first {k}: {100.0 * v['top' + str(k)] / st['nodes']:.1f} %" for k in (64, 256, 1024, 4096)) + f"  ({st['nodes'] / st['rays']:.1f} nodes per ray)")
 

@@ -41,6 +41,19 @@ PASSES = {
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
 }
+# passes for the workloads that read the scene from global memory (what binds a divergent gather: wave stalls, the texture addresser, the L1 tags, the L2): collected
+# like the others, each in its own run. TA / TCP / TCC counters are summed over their instances (the `_sum` derived names).
+GATHER_PASSES = {
+    "sq3": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_FLAT", "SQ_INSTS_FLAT", "SQ_INST_CYCLES_VMEM_RD", "SQ_WAVE_CYCLES"],
+    "ta": ["TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum"],
+    "ta2": ["TA_BUSY_avr", "TA_BUSY_max", "TA_TOTAL_WAVEFRONTS_sum", "TA_FLAT_WAVEFRONTS_sum"],
+    "tcp": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum"],
+    "tcp2": ["TCP_TOTAL_ACCESSES_sum", "TCP_TOTAL_READ_sum", "TCP_GATE_EN1_sum", "TCP_TA_TCP_STATE_READ_sum"],
+    "tcp3": ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCP_LATENCY_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_TCR_TCP_STALL_CYCLES_sum"],
+    "tcc": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_READ_sum"],
+    "tcc2": ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_DRAM_sum"],
+    "grbm": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
+}
 
 
 def run(cmd, log):
@@ -65,7 +78,9 @@ def counters(directory):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
-    ap.add_argument("--round", default="r03")
+    ap.add_argument("--round", default="r04")
+    ap.add_argument("--passes", default="", help="comma-separated pass names (default: the four standard passes; GATHER_PASSES names are accepted too, `gather` = all of them)")
+    ap.add_argument("--no-trace", action="store_true", help="skip the --kernel-trace --stats run (needs a bench_line.json from an earlier run under --out)")
     ap.add_argument("--reaggregate", action="store_true", help="no runs: rebuild the JSON and the summary from the per-pass CSVs (and bench lines) an earlier run left under --out")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -74,6 +89,11 @@ def main():
     result = json.loads(jpath.read_text()) if jpath.exists() else {}
     md = []
     digest = bench.source_digest()
+    allp = dict(PASSES); allp.update(GATHER_PASSES)
+    names = [n for n in a.passes.split(",") if n]
+    if "gather" in names:
+        names = [n for n in names if n != "gather"] + list(GATHER_PASSES)
+    passes = {n: allp[n] for n in names} if names else PASSES
     for wl, tree, integ, split, extra in CONFIGS:
         key = bench.pmc_key(wl, tree, integ, split, 0)
         if a.only and a.only not in key:
@@ -82,7 +102,7 @@ def main():
         args = ["bench.py", "--workload", wl, "--tree", tree, "--sample-split", str(split), "--no-cpu-baseline", "--no-workloads", "--no-host-api"] + extra
         d = out / tag; d.mkdir(exist_ok=True)
         print("==", key, flush=True)
-        if a.reaggregate:
+        if a.reaggregate or (a.no_trace and (d / "bench_line.json").exists()):
             if (d / "bench_line.json").exists():
                 bl = json.loads((d / "bench_line.json").read_text())
             elif key in result:          # an earlier version did not keep the line: rebuild the fields the summary needs from the JSON record
@@ -105,7 +125,9 @@ def main():
             rows = list(csv.reader(open(fcsv)))
             stats_rows = [rows[0]] + [r for r in rows[1:] if "terra_" in r[0] and "sincos24" not in r[0]]
         allc = {}; meta_r = {}; per_kernel = {}
-        for pname, ctrs in PASSES.items():
+        if key in result:            # passes of an earlier run (other pass names) are kept
+            allc.update({k: v for k, v in result[key].get("pmc", {}).items()})
+        for pname, ctrs in passes.items():
             if not a.reaggregate:
                 rc, so = run(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", str(d / pname), "--", "python3"] + args, d / f"{pname}.err")
                 if rc != 0:
@@ -132,7 +154,11 @@ def main():
         if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
             rec["fetch_size_kb"] = g("FETCH_SIZE"); rec["write_size_kb"] = g("WRITE_SIZE")
             rec["hbm_bytes_per_launch"] = int((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024)
-        rec["resources"] = meta_r
+        rec["resources"] = meta_r or result.get(key, {}).get("resources", {})
+        rec["pmc"] = dict(allc)      # every counter collected for the timed kernel, per launch (all passes so far)
+        for k2 in ("hbm_bytes_per_launch", "fetch_size_kb", "write_size_kb", "lane_util", "lds_bank_conflict_frac", "waves_per_simd", "kernel_name"):
+            if k2 not in rec and k2 in result.get(key, {}):
+                rec[k2] = result[key][k2]
         result[key] = rec
         jpath.write_text(json.dumps(result, indent=1))
         md.append(f"## {key}\n")
