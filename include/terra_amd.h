@@ -45,10 +45,40 @@ void        terra_amd_clear_first_error ( void );
 size_t      terra_amd_thread_staging_bytes ( void );
 
 /* Device selection for subsequent commits/renders issued by this thread's
-   scenes. One process drives one GPU in the multi-GPU layout. */
+   scenes: one device (one process per GPU is bench.py's layout, DESIGN.md "Multi-GPU"), or a set of devices driven from this process (below). */
 int  terra_amd_device_count ( void );
 int  terra_amd_set_device ( int device );
 int  terra_amd_get_device ( void );
+
+/* Several GPUs from ONE process (the layout of the reference's client: one process, tiles dealt to workers, satellite/src/Renderer.cpp:316-350).
+   terra_amd_set_devices() names the devices every scene committed from now on is replicated on (no duplicates; count 0 = back to the one device
+   of terra_amd_set_device); devices[0] is the primary device: it holds the staging frame and receives the gather. With more than one device
+   in the set, terra_render() on a host framebuffer
+     * shards a call that covers at least 256 x 256 pixels per device: device k renders the 64-pixel tiles t with terra_amd_shard_owner(t, N) == k,
+       and one gather -- RCCL over xGMI, loaded at run time (librccl.so.1) and issued by this library -- brings the packed tiles to the primary
+       device, which copies the rectangle to the host once;
+     * sends a smaller call (the reference client's 128-pixel tiles) whole to one device: the calling thread's -- threads are dealt to the
+       devices round-robin when they first call, so the client's eight workers drive eight GPUs.
+   The framebuffer does not depend on the device set (same pixels, same sums, bit for bit). terra_amd_render_multi() is the sharded form
+   called explicitly, for any rectangle and tile size (0 = 64) and any number of devices -- with ONE device in the set the same calls
+   run (a communicator of one rank, the gather a copy inside the device), which is how a one-GPU box tests it. */
+int  terra_amd_set_devices ( const int* devices, int count );
+int  terra_amd_get_devices ( int* out, int capacity );              /* returns the number of devices in the set (>= 1) */
+int  terra_amd_shard_owner ( size_t tile_index, int world );        /* the rank that renders tile `tile_index` (row-major in the rectangle) of `world` ranks */
+int  terra_amd_render_multi ( const TerraCamera* camera, HTerraScene scene, const TerraFramebuffer* framebuffer,
+                              size_t x, size_t y, size_t width, size_t height, size_t tile_size );
+typedef struct {
+    int      devices;               /* size of the set the scene was committed for */
+    int      device[16];            /* ... its first 16 members, primary first */
+    int      replicas;              /* device copies of the scene that exist (0: not committed / commit failed) */
+    uint64_t gathers;               /* gathers this scene's multi-device renders have issued */
+    uint64_t last_gather_bytes;     /* bytes the last one moved to the primary device (28 B per pixel of whole tiles, every rank's share) */
+    uint64_t process_collectives;   /* RCCL group calls issued by this process */
+    int      rccl_version;          /* ncclGetVersion() of the loaded library, 0 = not loaded (no multi-device render yet) */
+    int      communicator_ranks;    /* ranks of the cached communicator */
+    char     rccl_library[64];      /* the name it was loaded by */
+} TerraAmdMultiInfo;
+int  terra_amd_multi_info ( HTerraScene scene, TerraAmdMultiInfo* out );
 
 /* Frame seed F of the per-pixel random streams (DESIGN.md "Randomness"):
    replaces the reference's time(NULL)^&exit seed (src/Terra.c:679) and libc
@@ -108,6 +138,10 @@ int  terra_amd_get_tree_builder ( HTerraScene scene );
    that float rounding alone produces too rarely to test. While it is on, the shortcuts that rest on the commit-time containment proof (leaf-box cull, fast
    tree inside the coordinate range) are not taken and terra_amd_traversal_info() says so. */
 int  terra_amd_debug_shrink_reference_boxes ( HTerraScene scene, float amount );
+/* TEST HOOK, off by default (0): every launch of this scene plans `entries` more traversal-stack entries per lane than the tree needs (1 KB of LDS per entry and block):
+   lets a test drive the launch path of trees deeper than 64 KB of LDS per block -- which the reference's own builder only produces on inputs of pathological size -- with an
+   ordinary scene. The image does not change. A plan beyond what a block can hold fails the call with a message, as a real tree of that depth would. */
+int  terra_amd_debug_pad_stack ( HTerraScene scene, int entries );
 
 /* Sample split: how many lanes share one pixel. With split = S (a power of two up to 64; default 1) a render call of
    spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random

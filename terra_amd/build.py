@@ -17,11 +17,11 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libterra_amd.so"
 # (source, object name, extra flags): render_kernels.hip is compiled once per TERRA_TU value -- its kernel instances per template MODE -- so that the units build in parallel
-SOURCES = [("scene_host.cpp", "scene_host.cpp", []), ("tree_build.cpp", "tree_build.cpp", []),
+SOURCES = [("scene_host.cpp", "scene_host.cpp", []), ("tree_build.cpp", "tree_build.cpp", []), ("multi_gpu.cpp", "multi_gpu.cpp", []),
            ("render_kernels.hip", "render_kernels.tu0.hip", ["-DTERRA_TU=0"]), ("render_kernels.hip", "render_kernels.tu1.hip", ["-DTERRA_TU=1"]),
            ("render_kernels.hip", "render_kernels.tu2.hip", ["-DTERRA_TU=2"]), ("render_kernels.hip", "render_kernels.tu3.hip", ["-DTERRA_TU=3"]),
            ("unit_kernels.hip", "unit_kernels.hip", []), ("tree_build_device.hip", "tree_build_device.hip", [])]
-HEADERS = ["dev_types.h", "dev_math.h", "rng.h", "trace_device.h", "sampling_device.h", "kernels.h", "tree_build.h"]
+HEADERS = ["dev_types.h", "dev_math.h", "rng.h", "trace_device.h", "sampling_device.h", "kernels.h", "tree_build.h", "multi_gpu.h"]
 ARCH = os.environ.get("TERRA_AMD_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -38,6 +38,16 @@ struct DevNode {
 };
 static_assert ( sizeof ( DevNode ) == 64, "DevNode must be 64 bytes" );
 
+// A fast-tree node as the kernels read it (trace_device.h "MODE 2"): the planes of the two child boxes as binary16 rounded outward, times DevScene's
+// power-of-two scale, axis major and for both ray signs: q[2 * axis + 0] = { min0, max0, min1, max1 }, q[2 * axis + 1] = { max0, min0, max1, min1 };
+// child words as in DevNode (inner: node index; leaf: DEV_CHILD_LEAF | (count - 1) << 27 | first triangle); an empty slot is an inverted box.
+struct DevFastNode {
+    uint16_t q[6][4];
+    uint32_t child[2];
+    uint32_t spare[2];
+};
+static_assert ( sizeof ( DevFastNode ) == 64, "DevFastNode must be 64 bytes" );
+
 struct DevTri {
     float    a[3]; uint32_t object;
     float    b[3]; uint32_t tri_in_object;
@@ -106,10 +116,11 @@ struct DevScene {
     // optional second accelerator over the same triangles (terra_amd_set_tree_mode, DESIGN.md "Fast tree"):
     // 3-axis binned-SAH BVH2, leaves of up to 4 triangles; fast_tris is the soup in leaf order with
     // DevTri::pad = the triangle's rank in the REFERENCE tree's leaf visit order (the tie-break key)
-    const DevNode*     fast_nodes;
+    const DevNode*     fast_nodes;      // built as DevNode (min, max), then rewritten in place as DevFastNode: that is what the kernels traverse
     const DevTri*      fast_tris;
     uint32_t n_fast_nodes;
     int32_t  fast_max_stack;
+    float    fast_inv_scale;            // 1 / (the power of two DevFastNode's planes are stored times): the factor of the ray's inverse direction
     // scenes outside the coordinate range of the containment proof (DESIGN.md "Reachability"): the fast tree (boxes inflated to the rounding bound) finds the
     // candidates, and one is accepted only if the REFERENCE traversal would have reached it, i.e. if the slab tests of its ancestors in the reference tree pass.
     // ref_replay[q] (DevReplay, 32 B) = the box the reference tests before it visits inner node q -- stored in q's parent -- and that parent's index, so that one

@@ -71,7 +71,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.sc = sc;
     // [staged nodes][staged triangles][staged properties][stack][leaf list][parked words]  (sizes: terra_lds_bytes)
     float4* ln = lds;                                                // byte offset 0: a staged node's address is its stack word
-    float4* lt = ln + ( MODE >= 2 ? 4 : TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;      // MODE 2 stages a prefix of the fast tree as plain 64-B nodes
+    float4* lt = ln + ( TERRA_LDS_NODE_BYTES / 16 ) * lds_nodes;      // (fast-tree launches stage nothing: lds_nodes == lds_tris == 0)
     float4* lp = lt + 3 * lds_tris;
     // MODE 1 also stages what shading reads per hit: the materials, the light list and the per-triangle areas (scene_extra_lds_bytes: three 16-byte aligned sections)
     uint32_t* lm = reinterpret_cast<uint32_t*> ( lp + 4 * lds_tris );
@@ -87,10 +87,6 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
     const float4* gt = reinterpret_cast<const float4*> ( sc.tris );
     const float4* gp = reinterpret_cast<const float4*> ( sc.props );
-    if ( MODE >= 2 ) {        // hot nodes of the fast tree: its numbering is breadth first, so the first lds_nodes nodes are its top levels
-        const float4* fn = reinterpret_cast<const float4*> ( sc.fast_nodes );
-        for ( uint32_t i = tid; i < 4 * lds_nodes; i += TERRA_COL ) ln[i] = fn[i];
-    } else
     for ( uint32_t i = tid; i < lds_nodes; i += TERRA_COL ) {       // node i -> the axis-major, both-signs layout (trace_device.h "Staged node")
         const float4 q0 = gn[4 * i], q1 = gn[4 * i + 1], q2 = gn[4 * i + 2], q3 = gn[4 * i + 3];
         const float mn0[3] = { q0.x, q0.y, q0.z }, mx0[3] = { q0.w, q1.x, q1.y }, mn1[3] = { q1.z, q1.w, q2.x }, mx1[3] = { q2.y, q2.z, q2.w };
@@ -185,17 +181,14 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_EXIT_SHIFT      // leave the traversal when n >> shift of the n lanes that entered it have finished
 #define TERRA_DECOUPLED_EXIT_SHIFT 4
 #endif
-#ifndef TERRA_DECOUPLED_LDS      // also decouple the LDS-resident (small scene) kernels: measured SLOWER (Cornell 26.7 -> 32 ms at best,
-                                // profiles/r01_measurements/ab_dec_lds.log): there shading outweighs traversal, so it stays off
-#define TERRA_DECOUPLED_LDS 0
-#endif
 #ifndef TERRA_DECOUPLED_FAST     // ... and the fast-tree kernels (MODE 2)
 #define TERRA_DECOUPLED_FAST 1
 #endif
 #ifndef TERRA_FAST_EXIT_16THS    // MODE 2 leaves the traversal when this many 16ths of the lanes that entered it have finished (a ray is cheap there, so shading wants fuller waves)
 #define TERRA_FAST_EXIT_16THS 12
 #endif
-#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_LDS && ( M ) == 1 ) || ( TERRA_DECOUPLED_FAST && ( M ) >= 2 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
+// (LDS-resident scenes, MODE 1, keep the coupled loop: decoupled they measure 20 % slower -- shading outweighs traversal there; CHANGELOG.md round 1 / 2)
+#define TERRA_DECOUPLED(I, M) ( TERRA_DECOUPLED_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST && ( M ) >= 2 ) ) && ( ( I ) == 0 || ( I ) == 3 || ( I ) == 4 || ( I ) == 5 ) )
 // ... and Direct, whose one shadow ray per hit becomes a traversal job of its own (scenes without textured attributes)
 #ifndef TERRA_DECOUPLED_DIRECT_ENABLE
 #define TERRA_DECOUPLED_DIRECT_ENABLE 1
@@ -206,14 +199,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_FAST_MIS     // Direct + MIS on the fast tree is faster coupled (hall, 32 spp: 168.6 ms against 187.7 decoupled; profiles/r02_measurements/ab_fast_light.log)
 #define TERRA_DECOUPLED_FAST_MIS 0
 #endif
-#ifndef TERRA_DECOUPLED_LDS_DIRECT   // ... and on LDS-resident scenes (MODE 1): measured SLOWER (Cornell Direct 128 spp: 43.3 ms coupled, 54.9 decoupled waiting for all lanes,
-                                     // 55.2 at 12/16, 50.1 with 5 waves/SIMD; profiles/r02_measurements/ab_fast_light.log), so it stays off
-#define TERRA_DECOUPLED_LDS_DIRECT 0
-#endif
-#ifndef TERRA_LDS_EXIT_16THS
-#define TERRA_LDS_EXIT_16THS 16
-#endif
-#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) >= 2 ) || ( TERRA_DECOUPLED_LDS_DIRECT && ( M ) == 1 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
+#define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) >= 2 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )
 #ifndef TERRA_DECOUPLED_MIS_ENABLE
 #define TERRA_DECOUPLED_MIS_ENABLE 1
 #endif
@@ -276,7 +262,7 @@ template <int COUNT, int MODE>
 TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, Counters& c ) {
     const int n_trav = __popcll ( __ballot ( t.traversing ) );
     if ( n_trav == 0 ) return false;
-    int quota = MODE >= 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : MODE == 1 ? ( n_trav * TERRA_LDS_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
+    int quota = MODE >= 2 ? ( n_trav * TERRA_FAST_EXIT_16THS ) >> 4 : n_trav >> TERRA_DECOUPLED_EXIT_SHIFT; if ( quota < 1 ) quota = 1;
     const int exit_active = n_trav - quota;
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
@@ -360,11 +346,13 @@ TD bool job_pixel ( const DevRenderParams& p, uint32_t job, uint32_t& px, uint32
 }
 // aux: the lane's parked words (TERRA_AUX_WORDS rows of 256): [0], [256], [512] the job's radiance sum; [768] the job; [1024] the lane's draw count at the job's
 // start; row 5 holds, per wave, the pool {next job, end} at [1280 + 64 * wave + 0 / 1] relative to thread 0's column
-TD uint32_t* job_pool_of_wave ( float* aux_of_thread ) { return reinterpret_cast<uint32_t*> ( aux_of_thread - threadIdx.x ) + 1280 + ( threadIdx.x & ~63u ); }
+// (volatile: the pool is how the lanes of a wave tell each other which jobs are taken -- lane 0 of one group of callers writes it, another group reads it on a later call;
+//  a plain access would let the compiler keep a stale copy in a register across the render loop's back edge)
+TD volatile uint32_t* job_pool_of_wave ( float* aux_of_thread ) { return reinterpret_cast<volatile uint32_t*> ( aux_of_thread - threadIdx.x ) + 1280 + ( threadIdx.x & ~63u ); }
 TD void job_init_lane ( const DevRenderParams& p, float* aux ) {
     reinterpret_cast<uint32_t*> ( aux ) [768] = TERRA_JOB_NONE;
     if ( ( threadIdx.x & 63u ) == 0 ) {       // the wave's first pool
-        uint32_t* pool = job_pool_of_wave ( aux );
+        volatile uint32_t* pool = job_pool_of_wave ( aux );
         if ( p.job_queue ) { pool[0] = 0; pool[1] = 0; }      // empty: the first ask claims a batch from the queue like every later one. (No job is RESERVED for a block by its index:
                                                               // a block that the GPU only makes resident late -- when others have drained the queue -- finds nothing and leaves.)
         else {                                                // plain launch (no queue): the 64 jobs of the wave's own index
@@ -387,7 +375,7 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
         p.partials[ ( ( size_t ) chunk * ( p.job_blocks >> p.split_log2 ) + blk ) * 256 + ( fin & 255u )] = make_float4 ( aux[0], aux[256], aux[512], __uint_as_float ( COUNT == 2 ? c.rand_calls - auxu[1024] : 0u ) );
         auxu[768] = TERRA_JOB_NONE;
     }
-    uint32_t* pool = job_pool_of_wave ( aux );
+    volatile uint32_t* pool = job_pool_of_wave ( aux );
     const unsigned long long m = __ballot ( 1 );                 // the lanes here
     const uint32_t lane = threadIdx.x & 63u, n = ( uint32_t ) __popcll ( m ), ahead = ( uint32_t ) __popcll ( m & ( ( 1ull << lane ) - 1ull ) );
     const uint32_t total = p.job_blocks * 256u;
@@ -411,7 +399,7 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
     if ( !got ) { j.exhausted = true; return; }                  // the queue is monotone: a batch that does not cover the askers means nothing is left, ever
     uint32_t chunk;
     int prior_samples;
-    if constexpr ( TERRA_JOB_STREAM_TABLE && TABLE ) {
+    if ( TERRA_JOB_STREAM_TABLE && TABLE && p.job_streams ) {      // (no table: a launch whose table would not fit the scratch bound keys its streams here, like the kernels that wait on memory)
         const uint4 e1 = p.job_streams[2 * ( size_t ) job + 1];       // keyed by terra_job_streams_kernel (below): the job's pixel comes with it, the decode's divisions are not repeated here
         if ( e1.z == 0xffffffffu ) return;                                 // (a pixel outside the rectangle)
         const uint4 e0 = p.job_streams[2 * ( size_t ) job];
@@ -690,19 +678,14 @@ static size_t scene_extra_lds_bytes ( uint32_t n_objects, uint32_t n_lights, uin
     return ( ( ( size_t ) n_objects * sizeof ( DevMaterial ) + 15 ) & ~size_t ( 15 ) ) + ( size_t ) n_lights * sizeof ( DevLight ) + ( ( ( size_t ) n_tris * 4 + 15 ) & ~size_t ( 15 ) );
 }
 size_t terra_lds_bytes ( const DevRenderParams& p ) {
-    return ( size_t ) ( p.stack_depth + p.leaf_cap + ( p.lds_mode == 1 ? TERRA_AUX_WORDS_LDS : TERRA_AUX_WORDS ) ) * 1024 + ( size_t ) p.lds_nodes * ( p.lds_mode == 2 ? 64 : TERRA_LDS_NODE_BYTES ) + ( size_t ) p.lds_tris * ( 48 + 64 )
+    return ( size_t ) ( p.stack_depth + p.leaf_cap + ( p.lds_mode == 1 ? TERRA_AUX_WORDS_LDS : TERRA_AUX_WORDS ) ) * 1024 + ( size_t ) p.lds_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) p.lds_tris * ( 48 + 64 )
            + ( p.lds_mode == 1 ? scene_extra_lds_bytes ( p.scene.n_objects, p.scene.n_lights, p.scene.n_tris ) : 0 );
 }
-// fast tree (MODE 2): nodes of its breadth-first prefix staged per block. The kernel is latency bound (a ray's node fetches are a
-// dependent chain through L2 / Infinity Cache) and on the 97k-triangle hall the first 64 / 256 / 1024 nodes receive 39 / 57 / 70 % of
-// all node visits (profiles/r02_measurements/phase_hall_fast.log), so a small prefix shortens the chain more than the resident block
-// it may cost: A/B in profiles/r02_measurements/ab_prefix.log.
-#ifndef TERRA_FAST_PREFIX_NODES      // (tree_build.cpp numbers this many top-level nodes first)
-#define TERRA_FAST_PREFIX_NODES 64
-#endif
+// fast tree (MODE 2 / 3): nothing is staged. A lane holds at most one leaf (in a register), so there is no leaf list; the stack has the tree's depth + 1 entries.
+// (Rounds 2-3 staged the first 64 nodes as plain 64-byte nodes read through a flat load: +3.7 % then; the binary16 node's three sign-selected 8-byte reads per
+// step would each need their own 64-bit address for that, more than the prefix returns -- the top levels now come from the L1 like every other hot line.)
 void terra_plan_fast_tree ( DevRenderParams& p ) {
-    p.lds_mode = 2; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) ( p.scene.fast_max_stack < 1 ? 1 : p.scene.fast_max_stack );
-    p.lds_nodes = p.scene.n_fast_nodes < ( uint32_t ) TERRA_FAST_PREFIX_NODES ? p.scene.n_fast_nodes : ( uint32_t ) TERRA_FAST_PREFIX_NODES;
+    p.lds_mode = 2; p.lds_tris = 0; p.lds_nodes = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) ( p.scene.fast_max_stack < 1 ? 1 : p.scene.fast_max_stack );
 }
 
 // LDS plan. Small scenes (whole scene + stack + a leaf list of at least TERRA_LEAF_CAP_RESIDENT_MIN entries <= budget): stage
@@ -748,10 +731,19 @@ void terra_plan_lds ( DevRenderParams& p ) {
         int room = TERRA_LDS_CU_KB / blocks - ( int ) depth - TERRA_AUX_WORDS;       // KB per block left for the leaf list (2 KB of slack per CU)
         if ( room >= TERRA_LEAF_CAP_MIN || blocks == 1 ) { p.leaf_cap = ( uint32_t ) ( room > TERRA_LEAF_CAP_MAX ? TERRA_LEAF_CAP_MAX : ( room < 4 ? 4 : room ) ); break; }
     }
+    // a deep tree: keep the block within the 64 KB a launch may ask for without an opt-in while the leaf list keeps at least 4 entries; deeper still, the launch opts in
+    // (launch_instance: hipFuncAttributeMaxDynamicSharedMemorySize, one block per CU) up to TERRA_LDS_BLOCK_MAX_KB, beyond which terra_launch_render refuses with a message
+    while ( p.leaf_cap > 4 && terra_lds_bytes ( p ) > ( size_t ) 64 * 1024 ) --p.leaf_cap;
 }
 
 #endif
 
+#ifndef TERRA_LDS_BLOCK_MAX_KB      // the most dynamic LDS one block may opt in to (a CU's 160 KB less what the runtime keeps)
+#define TERRA_LDS_BLOCK_MAX_KB 156
+#endif
+#if TERRA_TU_HAS ( 0 )
+size_t terra_lds_block_limit ( void ) { return ( size_t ) TERRA_LDS_BLOCK_MAX_KB * 1024; }
+#endif
 // blocks of one kernel instance the GPU holds at once (occupancy x CUs), cached per (kernel, LDS size): the persistent grid
 static uint32_t resident_blocks ( const void* fn, size_t lds ) {
     struct Key { const void* fn; size_t lds; int dev; uint32_t blocks; };
@@ -768,6 +760,15 @@ static uint32_t resident_blocks ( const void* fn, size_t lds ) {
 template <int I, int COUNT, int MODE, int KINDS>
 static hipError_t launch_instance ( const DevRenderParams& p, size_t lds, hipStream_t stream ) {
     auto fn = terra_render_kernel<I, COUNT, MODE, KINDS>;
+    if ( lds > ( size_t ) 64 * 1024 ) {          // a traversal stack deeper than ~55 entries (deep reference tree, Morton-ordered tree over clustered geometry): opt in, once per kernel and size
+        if ( lds > ( size_t ) TERRA_LDS_BLOCK_MAX_KB * 1024 ) return hipErrorInvalidValue;      // (terra_launch_render checks first and says why)
+        static thread_local size_t opted[8] = { 0 }; int dev = 0; ( void ) hipGetDevice ( &dev );
+        if ( opted[dev & 7] < lds ) {
+            const hipError_t e = hipFuncSetAttribute ( reinterpret_cast<const void*> ( fn ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds );
+            if ( e != hipSuccess ) return e;
+            opted[dev & 7] = lds;
+        }
+    }
     uint32_t grid = p.job_blocks;
     if ( p.job_queue ) { const uint32_t cap = resident_blocks ( reinterpret_cast<const void*> ( fn ), lds ); if ( grid > cap ) grid = cap; }
     hipLaunchKernelGGL ( fn, dim3 ( grid ), dim3 ( 256 ), lds, stream, p );
@@ -862,7 +863,15 @@ hipError_t terra_launch_job_streams ( const DevRenderParams& p, hipStream_t stre
     hipLaunchKernelGGL ( terra_job_streams_kernel, dim3 ( p.job_blocks ), dim3 ( 256 ), 0, stream, p );
     return hipGetLastError();
 }
-size_t terra_job_streams_bytes ( const DevRenderParams& p ) { return ( TERRA_JOB_STREAM_TABLE && p.lds_mode == 1 ) ? ( size_t ) p.job_blocks * 256 * 32 : 0; }      // (p.job_blocks set)
+// (p.job_blocks set). Above TERRA_JOB_STREAM_TABLE_MAX_BYTES the launch goes without the table (in-kernel keying: the same streams, 2-3 % slower on the LDS-resident kernels): a 4K frame at
+// 64 lanes per pixel would otherwise ask for 17 GB of scratch per concurrent stream for a 3 % gain
+#ifndef TERRA_JOB_STREAM_TABLE_MAX_BYTES
+#define TERRA_JOB_STREAM_TABLE_MAX_BYTES ( size_t ( 4 ) << 30 )
+#endif
+size_t terra_job_streams_bytes ( const DevRenderParams& p ) {
+    const size_t bytes = ( TERRA_JOB_STREAM_TABLE && p.lds_mode == 1 ) ? ( size_t ) p.job_blocks * 256 * 32 : 0;
+    return bytes <= TERRA_JOB_STREAM_TABLE_MAX_BYTES ? bytes : 0;
+}
 hipError_t terra_launch_resolve ( const DevRenderParams& p, hipStream_t stream ) {
     uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return hipSuccess;

@@ -28,6 +28,7 @@
 #include "dev_types.h"
 #include "kernels.h"
 #include "tree_build.h"
+#include "multi_gpu.h"
 
 // ------------------------------------------------------------------------------
 // error channel
@@ -82,6 +83,36 @@ extern "C" int terra_amd_set_device ( int device ) {
     return 0;
 }
 extern "C" int terra_amd_get_device ( void ) { return g_device; }
+// The devices a scene committed from now on is replicated on (terra_amd_set_devices): empty = the one device above. devices[0] is the scene's primary device: it holds
+// the staging frame of terra_render() / terra_amd_render_multi() and receives the gather.
+static std::mutex g_devices_lock;
+static std::vector<int> g_devices;
+extern "C" int terra_amd_set_devices ( const int* devices, int count ) {
+    if ( count < 0 || count > 64 || ( count > 0 && !devices ) ) return fail ( kTerraAmdErrBadArgument, "terra_amd_set_devices: %d devices", count );
+    const int n = terra_amd_device_count();
+    for ( int i = 0; i < count; ++i ) {
+        if ( devices[i] < 0 || devices[i] >= n ) return fail ( kTerraAmdErrNoDevice, "device %d not available (%d visible)", devices[i], n );
+        for ( int j = 0; j < i; ++j ) if ( devices[j] == devices[i] ) return fail ( kTerraAmdErrBadArgument, "device %d is listed twice", devices[i] );
+    }
+    std::lock_guard<std::mutex> g ( g_devices_lock );
+    const std::vector<int> now ( devices, devices + count );
+    if ( now != g_devices ) multigpu::forget_communicators();
+    g_devices = now;
+    if ( count > 0 ) g_device = devices[0];
+    return 0;
+}
+extern "C" int terra_amd_get_devices ( int* out, int capacity ) {
+    std::lock_guard<std::mutex> g ( g_devices_lock );
+    const int n = g_devices.empty() ? 1 : ( int ) g_devices.size();
+    for ( int i = 0; i < n && i < capacity && out; ++i ) out[i] = g_devices.empty() ? g_device : g_devices[ ( size_t ) i];
+    return n;
+}
+// which device of `world` renders tile t of a frame: the shard rule of the render kernels (DevRenderParams::rank / world), of bench.py's ranks and of
+// terra_amd_render_multi -- the reference deals tiles to its worker threads the same way (satellite/src/Renderer.cpp:316-350)
+extern "C" int terra_amd_shard_owner ( size_t tile_index, int world ) {
+    if ( world < 1 ) return fail ( kTerraAmdErrBadArgument, "bad shard arguments" );
+    return ( int ) ( tile_index % ( size_t ) world );
+}
 
 // ------------------------------------------------------------------------------
 // system
@@ -245,8 +276,7 @@ struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 #endif
 #define TERRA_REACH_MAX_COORD 1e6f       // beyond it (c - o) x 2^100 (the fast tree's clamped slab test) approaches the binary32 range: replica
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
-#define TERRA_FAST_STACK_LDS_LIMIT ( 64 * 1024 )   // dynamic LDS a block may ask for without an opt-in; a fast-tree launch needs (depth + aux words) KB + its staged node prefix
-#define TERRA_FAST_STACK_AUX_KB 6                   // render_kernels.hip TERRA_AUX_WORDS
+#define TERRA_FAST_STACK_AUX_KB 6                   // render_kernels.hip TERRA_AUX_WORDS: a fast-tree launch needs (depth + aux words) KB of LDS per block
 struct Scene {
     TerraSceneOptions opts, new_opts;
     TerraObject* objects = nullptr; size_t objects_pop = 0, objects_cap = 0;
@@ -257,9 +287,16 @@ struct Scene {
     std::vector<HostNode> nodes; int max_stack = 1;
     std::vector<HostLight> lights; size_t lights_triangles_count = 0;
     std::vector<uint32_t> first_tri;     // per object
-    // device replica
+    // device replica (of the primary device, `device`)
     DevScene dev; void* d_blob = nullptr; size_t d_bytes = 0;
     unsigned long long* d_counters = nullptr;
+    // ... and of the other devices of the set the scene was committed for (terra_amd_set_devices): byte copies of the blob with the pointers rebased
+    struct Replica { int device = -1; DevScene dev; void* d_blob = nullptr; unsigned long long* d_counters = nullptr; float* d_env_dist = nullptr; };
+    std::vector<Replica> extra;
+    std::vector<int> devices;           // the set, primary first (size 1: single-device scene)
+    std::vector<DevTexture> tdesc_host; size_t o_tdesc = 0, blob_bytes = 0, env_dist_floats = 0;      // what replicate() needs of the upload's layout
+    struct MultiCtx* multi = nullptr;   // streams / staging frames / packed buffers of terra_amd_render_multi, one set per device (made on first use)
+    std::mutex multi_lock;              // a multi-device render owns every device of the set: one at a time per scene
     std::atomic<uint64_t> launches { 0 }, stat_pixels { 0 }, stat_samples { 0 };     // terra_render() is called from several threads at once
     int uniform_attr_count = -1;        // attributes_count shared by every material, or -1
     uint32_t bsdf_kinds = 0;            // mask of preset kinds in the committed scene
@@ -285,6 +322,7 @@ struct Scene {
     bool sampler_integration = false;   // terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce (a launch parameter)
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
+    int test_pad_stack = 0;                         // terra_amd_debug_pad_stack (tests only): extra stack entries every launch plans
     float test_shrink_reference_boxes = 0.f;       // terra_amd_debug_shrink_reference_boxes (tests only): the device copy of the reference tree's boxes is shrunk by this much
 };
 
@@ -339,6 +377,11 @@ extern "C" int terra_amd_debug_shrink_reference_boxes ( HTerraScene h, float amo
     if ( s->test_shrink_reference_boxes != amount ) { s->test_shrink_reference_boxes = amount; s->dirty_objects = true; s->committed = false; }
     return 0;
 }
+extern "C" int terra_amd_debug_pad_stack ( HTerraScene h, int entries ) {
+    if ( entries < 0 || entries > 4096 ) return fail ( kTerraAmdErrBadArgument, "stack padding must be 0 .. 4096 entries" );
+    S ( h )->test_pad_stack = entries;
+    return 0;
+}
 extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* out ) {
     Scene* s = S ( h );
     if ( !out ) return fail ( kTerraAmdErrBadArgument, "null output" );
@@ -376,7 +419,33 @@ extern "C" int terra_amd_get_sampler_integration ( HTerraScene h ) { return S ( 
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
 extern "C" uint64_t terra_amd_get_frame_seed ( HTerraScene h ) { return S ( h )->frame_seed; }
 
+// per device of a multi-device scene: its stream, its staging frame (the rectangle of the call, 28 B per pixel), its packed tiles; on the primary device also
+// the receive buffer of the gather (every rank's packed tiles, one after the other)
+struct MultiCtx {
+    struct PerDevice { int device = -1; hipStream_t stream = nullptr; void* d_pixels = nullptr; void* d_results = nullptr; size_t cap_px = 0; float* d_packed = nullptr; size_t packed_floats = 0; };
+    std::vector<PerDevice> dev; float* d_recv = nullptr; size_t recv_floats = 0;
+    uint64_t gathers = 0, last_gather_bytes = 0;
+    void release() {
+        for ( PerDevice& q : dev ) {
+            if ( q.device < 0 || hipSetDevice ( q.device ) != hipSuccess ) continue;
+            if ( q.stream ) { ( void ) hipStreamSynchronize ( q.stream ); ( void ) hipStreamDestroy ( q.stream ); }
+            if ( q.d_pixels ) ( void ) hipFree ( q.d_pixels );
+            if ( q.d_results ) ( void ) hipFree ( q.d_results );
+            if ( q.d_packed ) ( void ) hipFree ( q.d_packed );
+            if ( &q == &dev[0] && d_recv ) ( void ) hipFree ( d_recv );
+        }
+        dev.clear(); d_recv = nullptr; recv_floats = 0;
+    }
+};
 static void release_device ( Scene* s ) {
+    if ( s->multi ) { s->multi->release(); delete s->multi; s->multi = nullptr; }
+    for ( Scene::Replica& r : s->extra ) {
+        if ( r.device < 0 || hipSetDevice ( r.device ) != hipSuccess ) continue;
+        if ( r.d_env_dist ) ( void ) hipFree ( r.d_env_dist );
+        if ( r.d_blob ) ( void ) hipFree ( r.d_blob );
+        if ( r.d_counters ) ( void ) hipFree ( r.d_counters );
+    }
+    s->extra.clear();
     if ( s->d_blob || s->d_counters || s->d_env_dist ) {
         ( void ) hipSetDevice ( s->device );
         if ( s->d_env_dist ) ( void ) hipFree ( s->d_env_dist );
@@ -423,8 +492,8 @@ static bool is_phong ( const TerraBSDF& b ) { return b.sample == terra_bsdf_phon
 // origin and a vertex: translating and shearing the vertices perturbs them by <= 4 u D per coordinate, the sign of an edge function
 // can be wrong only within ~2 u D of the edge, the slab test's t values carry <= 3 roundings (<= ~6 u D in position), the box itself
 // is rounded by <= u R: together < 16 u D, D <= 2 sqrt(3) R for origins and vertices inside [-R, R]^3, i.e. < 56 u R.
-// The fast tree's boxes are traversed as (centre, half extent) (tree_build_device.hip): the new box contains the old one, and
-// t = (c - o) * inv -+ h * |inv| carries 4 roundings instead of 3 (<= ~8 u D): < 18 u D, i.e. < 63 u R.
+// The fast tree's boxes are traversed as binary16 planes rounded outward (tree_build_device.hip tb_half_planes_kernel): the new box contains the old one, and
+// t = fma ( plane, inv, -(o * inv) ) carries 2 roundings (the product o * inv, worth u |o| in position, and the fma's), fewer than the 3 of the reference form.
 // The check demands 128 u R <= 1e-4 (a factor 2 beyond those estimates): R <= 13.1 scene units, for the vertices (at commit) and for
 // the camera position (per call). Scenes or cameras outside that range run in replica mode. tools/fuzz_vs_oracle.py scales scenes
 // through and beyond the limit (FUZZ_SCALE) to exercise both sides.
@@ -786,9 +855,9 @@ static int upload_scene ( Scene* s ) {
     if ( s->tree_mode == 2 && s->reach && !s->use_fast ) { s->reach = false; }
     // the stack of a fast-tree launch is one KB of LDS per entry and block (terra_plan_fast_tree): a tree too deep for the LDS a block may ask for (clustered or
     // coincident geometry under the device builder's Morton order can reach ~60 levels) cannot launch -- such a scene keeps the reference tree, which always fits
-    auto fast_stack_fits = [] ( int depth ) { return ( size_t ) ( depth + TERRA_FAST_STACK_AUX_KB ) * 1024 + 64 * 64 <= ( size_t ) TERRA_FAST_STACK_LDS_LIMIT; };
+    auto fast_stack_fits = [] ( int depth ) { return ( size_t ) ( depth + TERRA_FAST_STACK_AUX_KB ) * 1024 <= terra_lds_block_limit(); };
     if ( s->use_fast && !s->fast_on_device && !fast_stack_fits ( s->fast_max_stack ) ) {
-        char b[160]; snprintf ( b, sizeof b, "fast tree needs a traversal stack of %d entries, more LDS than a block may hold: reference tree, replica traversal", s->fast_max_stack );
+        char b[200]; snprintf ( b, sizeof b, "fast tree needs a traversal stack of %d entries, more LDS than a block may hold: %s", s->fast_max_stack, s->cull_ok ? "reference tree with the leaf-box cull (global memory)" : "reference tree, replica traversal" );
         s->use_fast = false; s->reach = false; s->tree_note = b; fnodes.clear(); ftris.clear(); soup_of_fast.clear(); s->fast_nodes = 0; s->fast_max_stack = 1;
     }
     if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : ( resident ? "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)" : s->tree_note );
@@ -851,7 +920,7 @@ static int upload_scene ( Scene* s ) {
         phase ( "fast tree (device LBVH)", t_phase );
         s->fast_nodes = built_nodes; s->fast_max_stack = built_stack; have_fast = true;
         if ( !fast_stack_fits ( built_stack ) ) {          // (a Morton-ordered tree over clustered or coincident geometry can be ~60 levels deep)
-            char b[200]; snprintf ( b, sizeof b, "device-built fast tree needs a traversal stack of %d entries, more LDS than a block may hold: reference tree, replica traversal", built_stack );
+            char b[240]; snprintf ( b, sizeof b, "device-built fast tree needs a traversal stack of %d entries, more LDS than a block may hold: %s", built_stack, s->cull_ok ? "reference tree with the leaf-box cull (global memory)" : "reference tree, replica traversal" );
             s->use_fast = false; s->reach = false; s->fast_on_device = false; s->tree_note = b; s->fast_nodes = 0; s->fast_max_stack = 1; have_fast = false;
             if ( s->tree_mode == 2 && auto_ok && resident ) s->tree_note = "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
         } else if ( s->tree_mode == 2 || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {          // the culling relies on containment: read the tree back and check it like the host-built one
@@ -876,8 +945,14 @@ static int upload_scene ( Scene* s ) {
             }
         }
     }
-    if ( have_fast && s->fast_nodes ) {       // boxes as (centre, half extent): what the kernels traverse; everything above checked the (min, max) form
-        hipError_t e = terra_fast_nodes_center_extent ( ( DevNode* ) ( base + o_fn ), s->fast_nodes, nullptr );
+    float fast_scale = 1.f;
+    if ( have_fast && s->fast_nodes ) {       // boxes as binary16 planes for both ray signs (DevFastNode): what the kernels traverse; everything above checked the (min, max) form
+        // every plane times a power of two that brings the largest of them (|coordinate| + box margin) below 2^14: binary16 reaches 65,504, and a power of two changes
+        // no bit of plane or t value -- the kernel divides the ray's inverse direction by the same factor (DevScene::fast_inv_scale)
+        const float reach = s->coord_max + 1e-4f + fast_extra;
+        if ( std::isfinite ( reach ) ) while ( reach * fast_scale >= 16384.f && fast_scale > 0x1p-100f ) fast_scale *= 0.5f;
+        if ( s->fast_nodes >= ( 1u << 26 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address nodes by a 32-bit byte offset (at most 2^26 nodes)", s->fast_nodes );
+        hipError_t e = terra_fast_nodes_half_planes ( ( DevNode* ) ( base + o_fn ), s->fast_nodes, fast_scale, nullptr );
         if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "fast tree conversion: %s", hipGetErrorString ( e ) );
     }
     for ( size_t k = 0; k < textures.size(); ++k ) {
@@ -888,13 +963,13 @@ static int upload_scene ( Scene* s ) {
     }
     if ( !tdesc.empty() ) HIP_TRY ( hipMemcpy ( base + o_td, tdesc.data(), tdesc.size() * sizeof ( DevTexture ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     s->dev.textures = tdesc.empty() ? nullptr : ( const DevTexture* ) ( base + o_td );
-    s->d_bytes = total;
+    s->d_bytes = total; s->blob_bytes = total; s->o_tdesc = o_td; s->tdesc_host = tdesc; s->env_dist_floats = 0;
     s->dev.nodes = ( const DevNode* ) ( base + o_nodes ); s->dev.tris = ( const DevTri* ) ( base + o_tris ); s->dev.props = ( const DevProps* ) ( base + o_props );
     s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
     s->dev.n_nodes = ( uint32_t ) nodes.size(); s->dev.n_tris = ( uint32_t ) ntri; s->dev.n_objects = ( uint32_t ) nobj; s->dev.n_lights = ( uint32_t ) s->lights.size();
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
     s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
-    s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack;
+    s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack; s->dev.fast_inv_scale = 1.f / fast_scale;
     s->dev.reach = ( s->reach && have_fast && !reach_tabs.leaf_parent.empty() ) ? 1u : 0u;
     s->dev.ref_replay = s->dev.reach ? ( const DevReplay* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
     s->dev.env_mode = env_mode; s->dev.env_tex = env_tex; memcpy ( s->dev.env_color, env_color, sizeof env_color );
@@ -925,12 +1000,49 @@ static int upload_scene ( Scene* s ) {
         const float integral = row_init ( row_f, ny, row_cdf );
         HIP_TRY ( hipMalloc ( ( void** ) &s->d_env_dist, tab.size() * sizeof ( float ) ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( s->d_env_dist, tab.data(), tab.size() * sizeof ( float ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
-        s->d_bytes += tab.size() * sizeof ( float );
+        s->d_bytes += tab.size() * sizeof ( float ); s->env_dist_floats = tab.size();
         s->dev.env_f = s->d_env_dist; s->dev.env_cdf = s->d_env_dist + cells; s->dev.env_row_f = s->d_env_dist + 2 * cells; s->dev.env_row_cdf = s->d_env_dist + 2 * cells + ny;
         s->dev.env_nx = ( uint32_t ) nx; s->dev.env_ny = ( uint32_t ) ny; s->dev.env_integral = integral;
         s->dev.env_monotone = ( mono && integral > 0.f && integral <= FLT_MAX ) ? 1u : 0u;      // then every running sum is non-decreasing: bisection finds the scan's bucket
     }
     s->device_ok = true;
+    return 0;
+}
+
+// The committed scene on the other devices of the set: the primary device's finished blob (trees built, boxes converted, tables filled) copied device to device,
+// every pointer into it moved by the difference of the two base addresses, the texture descriptors -- which hold absolute addresses -- written again.
+static int replicate_scene ( Scene* s ) {
+    const char* base0 = ( const char* ) s->d_blob;
+    for ( size_t k = 1; k < s->devices.size(); ++k ) {
+        Scene::Replica r; r.device = s->devices[k];
+        HIP_TRY ( hipSetDevice ( r.device ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMalloc ( &r.d_blob, s->blob_bytes ), kTerraAmdErrNoDevice );
+        s->extra.push_back ( r );                                   // (owned from here on: release_device frees it whatever fails below)
+        Scene::Replica& q = s->extra.back();
+        HIP_TRY ( hipMemcpyPeer ( q.d_blob, q.device, s->d_blob, s->device, s->blob_bytes ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMalloc ( ( void** ) &q.d_counters, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
+        HIP_TRY ( hipMemset ( q.d_counters, 0, kCtrCount * sizeof ( unsigned long long ) ), kTerraAmdErrNoDevice );
+        char* base = ( char* ) q.d_blob;
+        auto move = [&] ( const void* p ) -> const void* { return p ? ( const void* ) ( base + ( ( const char* ) p - base0 ) ) : nullptr; };
+        q.dev = s->dev;
+        q.dev.nodes = ( const DevNode* ) move ( s->dev.nodes ); q.dev.tris = ( const DevTri* ) move ( s->dev.tris ); q.dev.props = ( const DevProps* ) move ( s->dev.props );
+        q.dev.mats = ( const DevMaterial* ) move ( s->dev.mats ); q.dev.lights = ( const DevLight* ) move ( s->dev.lights ); q.dev.tri_area = ( const float* ) move ( s->dev.tri_area );
+        q.dev.textures = ( const DevTexture* ) move ( s->dev.textures ); q.dev.fast_nodes = ( const DevNode* ) move ( s->dev.fast_nodes ); q.dev.fast_tris = ( const DevTri* ) move ( s->dev.fast_tris );
+        q.dev.ref_replay = ( const DevReplay* ) move ( s->dev.ref_replay ); q.dev.fast_leaf_parent = ( const uint32_t* ) move ( s->dev.fast_leaf_parent ); q.dev.fast_leaf_mask = ( const uint32_t* ) move ( s->dev.fast_leaf_mask );
+        if ( !s->tdesc_host.empty() ) {
+            std::vector<DevTexture> td = s->tdesc_host;
+            for ( DevTexture& t : td ) t.data = move ( t.data );
+            HIP_TRY ( hipMemcpy ( base + s->o_tdesc, td.data(), td.size() * sizeof ( DevTexture ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+        }
+        if ( s->d_env_dist && s->env_dist_floats ) {
+            HIP_TRY ( hipMalloc ( ( void** ) &q.d_env_dist, s->env_dist_floats * sizeof ( float ) ), kTerraAmdErrNoDevice );
+            HIP_TRY ( hipMemcpyPeer ( q.d_env_dist, q.device, s->d_env_dist, s->device, s->env_dist_floats * sizeof ( float ) ), kTerraAmdErrNoDevice );
+            auto emove = [&] ( const float* p ) { return p ? q.d_env_dist + ( p - s->d_env_dist ) : nullptr; };
+            q.dev.env_f = emove ( s->dev.env_f ); q.dev.env_cdf = emove ( s->dev.env_cdf ); q.dev.env_row_f = emove ( s->dev.env_row_f ); q.dev.env_row_cdf = emove ( s->dev.env_row_cdf );
+        }
+        q.dev.sincos24 = sincos_table_of ( q.device );
+    }
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     return 0;
 }
 
@@ -968,7 +1080,15 @@ extern "C" void terra_scene_commit ( HTerraScene h ) {
     // the "Lo +=" is commented out), so by default neither a constant nor a textured environment reaches the image and
     // nothing is uploaded for it; terra_amd_set_environment_lighting(scene, 1) turns that line on (upload_scene binds it).
     // options travel as kernel arguments; geometry/material/light changes need a new replica
-    if ( ( rebuild || relight || env_changed || !s->device_ok ) && upload_scene ( s ) != 0 ) { s->commit_error = g_last_error; s->device_ok = false; }
+    std::vector<int> set;
+    { std::lock_guard<std::mutex> g ( g_devices_lock ); set = g_devices; }
+    if ( set.empty() ) set.push_back ( g_device );
+    const bool set_changed = set != s->devices;          // (terra_amd_set_devices / terra_amd_set_device since the last commit: the replicas move)
+    if ( rebuild || relight || env_changed || !s->device_ok || set_changed ) {
+        if ( upload_scene ( s ) != 0 ) { s->commit_error = g_last_error; s->device_ok = false; return; }
+        s->devices = set;
+        if ( set.size() > 1 && replicate_scene ( s ) != 0 ) { s->commit_error = g_last_error; release_device ( s ); }
+    }
 }
 
 extern "C" int terra_amd_scene_info ( HTerraScene h, TerraAmdSceneInfo* out ) {
@@ -1038,15 +1158,16 @@ static uint32_t effective_spp ( const TerraSceneOptions& o ) {
     return ( uint32_t ) spp;
 }
 
+// replica: which device's copy of the scene the launch reads (nullptr: the primary device's)
 static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t fb_h, size_t x, size_t y, size_t w, size_t h,
-                         size_t tile, int rank, int world, DevRenderParams& p ) {
+                         size_t tile, int rank, int world, DevRenderParams& p, const Scene::Replica* replica = nullptr ) {
     if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "terra_scene_commit has not run since the scene changed" );
     if ( !s->device_ok ) return fail ( kTerraAmdErrNoDevice, "scene has no device replica: %s", s->commit_error.c_str() );
     if ( !cam || w == 0 || h == 0 || x + w > fb_w || y + h > fb_h ) return fail ( kTerraAmdErrBadArgument, "bad tile rectangle %zu,%zu %zux%zu in %zux%zu", x, y, w, h, fb_w, fb_h );
     if ( tile == 0 || tile % 16 != 0 ) return fail ( kTerraAmdErrBadArgument, "tile_size %zu must be a positive multiple of 16", tile );
     if ( world < 1 || rank < 0 || rank >= world ) return fail ( kTerraAmdErrBadArgument, "bad shard %d/%d", rank, world );
     memset ( &p, 0, sizeof p );
-    p.scene = s->dev;
+    p.scene = replica ? replica->dev : s->dev;
     // camera frame, reference src/Terra.c:1770-1781
     TerraFloat3 z = terra_normf3 ( &cam->direction );
     TerraFloat3 xa = terra_crossf3 ( &cam->up, &z ); xa = terra_normf3 ( &xa );
@@ -1070,13 +1191,14 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     if ( ( p.integrator == kTerraIntegratorDirect || p.integrator == kTerraIntegratorDirectMis || p.integrator == kTerraIntegratorDebugMisWeights ) && s->lights.empty() )
         return fail ( kTerraAmdErrBadArgument, "integrator %d needs at least one emissive object (the reference asserts, src/Terra.c:1617)", p.integrator );
     p.frame_seed = s->frame_seed;
-    p.counters = s->d_counters;
+    p.counters = replica ? replica->d_counters : s->d_counters;
     terra_plan_lds ( p );
     // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
     const bool cam_ok = ( s->reach || s->reach_cull ) ? ( fabsf ( p.cam_pos[0] ) <= s->reach_limit && fabsf ( p.cam_pos[1] ) <= s->reach_limit && fabsf ( p.cam_pos[2] ) <= s->reach_limit ) : coords_within_margin ( p.cam_pos, 3 );
-    if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) {
-        terra_plan_fast_tree ( p );
-        if ( s->fast_on_device ) p.lds_nodes = 0;      // the device-built tree is not numbered top-levels-first: nothing worth staging
+    if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) terra_plan_fast_tree ( p );
+    if ( s->test_pad_stack > 0 && p.lds_mode != 1 ) {          // TEST HOOK: a deeper stack than the tree needs (the LDS-resident plan is sized to the byte and stays as it is)
+        p.stack_depth += ( uint32_t ) s->test_pad_stack;
+        while ( p.leaf_cap > 4 && terra_lds_bytes ( p ) > ( size_t ) 64 * 1024 ) --p.leaf_cap;      // (what terra_plan_lds does for a deep tree)
     }
     p.leaf_cull = ( s->cull_ok && cam_ok && p.lds_mode != 2 ) ? 1u : 0u;
     p.fused_slab = ( p.leaf_cull && !s->reach_cull ) ? 1u : 0u;      // (out of range only the rebuilt LEAF boxes carry a margin: the inner boxes are tested exactly as the reference tests them)
@@ -1117,7 +1239,7 @@ static void account_launch ( Scene* s, const DevRenderParams& p ) {
 // sums into the pixels in chunk order and tonemaps (DevRenderParams::split; split == 1: one chunk per pixel).
 struct ThreadSlot;
 static void* slot_scratch ( ThreadSlot* slot, size_t bytes );
-static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, ThreadSlot* slot = nullptr ) {
+static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, ThreadSlot* slot = nullptr, int device = -1 ) {      // device: the (current) device of the launch, -1 = the scene's primary
     uint32_t split = s->sample_split;
     const uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return 0;
@@ -1132,11 +1254,12 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     }
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
     if ( split < 1 ) split = 1;
-    static thread_local int pool_device = -1;
-    if ( pool_device != s->device ) {        // keep freed scratch cached in the device's default pool instead of returning it to the OS at every sync
+    if ( device < 0 ) device = s->device;
+    static thread_local uint64_t pool_kept = 0;          // (bit d: done for device d)
+    if ( device < 64 && ! ( pool_kept >> device & 1ull ) ) {        // keep freed scratch cached in the device's default pool instead of returning it to the OS at every sync
         hipMemPool_t pool;
-        if ( hipDeviceGetDefaultMemPool ( &pool, s->device ) == hipSuccess ) { uint64_t keep = ~0ull; ( void ) hipMemPoolSetAttribute ( pool, hipMemPoolAttrReleaseThreshold, &keep ); }
-        pool_device = s->device;
+        if ( hipDeviceGetDefaultMemPool ( &pool, device ) == hipSuccess ) { uint64_t keep = ~0ull; ( void ) hipMemPoolSetAttribute ( pool, hipMemPoolAttrReleaseThreshold, &keep ); }
+        pool_kept |= 1ull << device;
     }
     const size_t header = 256;                                     // the job queue word (+ padding that keeps the partials 256-byte aligned)
     const size_t partial_bytes = ( size_t ) split * blocks * 256 * sizeof ( float4 );
@@ -1163,6 +1286,10 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
             return fail ( kTerraAmdErrBadArgument, "render rectangle too large for one launch (%u blocks x split %u): render it in several calls", blocks, split );
         }
         p.job_div_bpt2 = magic ( bpt2 ); p.job_div_tiles_x = magic ( tiles_x ); p.job_div_bpt = magic ( bpt ); p.job_tiles_x = ( uint32_t ) tiles_x;
+    }
+    if ( terra_lds_bytes ( p ) > terra_lds_block_limit() ) {          // (a reference tree hundreds of levels deep: nothing this library can launch)
+        if ( pooled ) ( void ) hipFreeAsync ( scratch, stream );
+        return fail ( kTerraAmdErrUnsupported, "the traversal stack of this scene's tree (%u entries) needs %zu KB of LDS per block, more than the %zu KB a block can have", p.stack_depth, terra_lds_bytes ( p ) / 1024, terra_lds_block_limit() / 1024 );
     }
     if ( e == hipSuccess ) e = terra_launch_job_streams ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_render ( p, stream );
@@ -1313,12 +1440,27 @@ static int slot_prepare ( int device, size_t npx ) {
 }
 extern "C" size_t terra_amd_thread_staging_bytes ( void ) { return t_slot.cap_px * 28; }
 
+static int render_host_multi ( const TerraCamera* cam, Scene* s, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t h, size_t tile );
+static std::atomic<int> g_thread_ordinals { 0 };
 static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t h ) {
     if ( !fb || !fb->pixels || !fb->results ) return fail ( kTerraAmdErrBadArgument, "null framebuffer" );
+    // A scene committed for several devices (terra_amd_set_devices). A call that covers enough of a frame to give every device a fair share of 64-pixel tiles is
+    // sharded over them and gathered (render_host_multi); a small one -- the reference client's 128-pixel tiles, called from its worker threads
+    // (satellite/src/Renderer.cpp:70-98,316-350) -- goes whole to ONE device, the calling thread's: threads are dealt to the devices round-robin when they first call, so
+    // eight workers drive eight GPUs and a thread's stream and staging buffers stay on one device.
+    const Scene::Replica* replica = nullptr;
+    if ( s->devices.size() > 1 && s->device_ok ) {
+        if ( w * h >= ( size_t ) 256 * 256 * s->devices.size() ) return render_host_multi ( cam, s, fb, x, y, w, h, 64 );
+        static thread_local int ordinal = -1;
+        if ( ordinal < 0 ) ordinal = g_thread_ordinals.fetch_add ( 1, std::memory_order_relaxed );
+        const size_t k = ( size_t ) ordinal % s->devices.size();
+        if ( k > 0 && k - 1 < s->extra.size() ) replica = &s->extra[k - 1];
+    }
+    const int device = replica ? replica->device : s->device;
     DevRenderParams p;
-    int rc = fill_params ( s, cam, fb->width, fb->height, x, y, w, h, 64, 0, 1, p );
+    int rc = fill_params ( s, cam, fb->width, fb->height, x, y, w, h, 64, 0, 1, p, replica );
     if ( rc ) return rc;
-    rc = slot_prepare ( s->device, w * h );
+    rc = slot_prepare ( device, w * h );
     if ( rc ) return rc;
     ThreadSlot& t = t_slot;
     // the staging buffer holds the rectangle only (rows of w pixels); the kernel addresses it through st_x / st_y / st_pitch while
@@ -1329,11 +1471,108 @@ static int render_host ( const TerraCamera* cam, Scene* s, const TerraFramebuffe
     char* hpix = ( char* ) fb->pixels + ( y * fb->width + x ) * 12;
     HIP_TRY ( hipMemcpy2DAsync ( t.d_results, w * 16, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, t.stream ), kTerraAmdErrLaunch );
     p.pixels = ( float* ) t.d_pixels; p.results = t.d_results; p.rand_calls = nullptr;
-    if ( int lrc = launch_render ( s, p, t.stream, &t ) ) return lrc;
+    if ( int lrc = launch_render ( s, p, t.stream, &t, device ) ) return lrc;
     HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, t.d_results, w * 16, w * 16, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, t.d_pixels, w * 12, w * 12, h, hipMemcpyDeviceToHost, t.stream ), kTerraAmdErrLaunch );
     HIP_TRY ( hipStreamSynchronize ( t.stream ), kTerraAmdErrLaunch );
     account_launch ( s, p );
+    return 0;
+}
+
+// terra_render() over the scene's device set from one process: device k renders the tiles t with t % N == k of the rectangle (terra_amd_shard_owner; the same kernels
+// with DevRenderParams::rank / world set) into its own staging frame, packs them, and ONE gather -- RCCL over xGMI, issued from here (multi_gpu.cpp) -- brings every
+// rank's packed tiles to the primary device, which unpacks them into its staging frame and copies the rectangle to the host once. The reference's client shards tiles over
+// worker threads of one process the same way (satellite/src/Renderer.cpp:316-350). The running sums of the rectangle go up to every device first (they key the random
+// streams and are accumulated on, src/Terra.c:570-574): 16 B per pixel and device over each device's own PCIe link.
+// With ONE device in the set the same calls run: a communicator of one rank, the gather a copy inside the device.
+static int render_host_multi ( const TerraCamera* cam, Scene* s, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t h, size_t tile ) {
+    if ( !fb || !fb->pixels || !fb->results ) return fail ( kTerraAmdErrBadArgument, "null framebuffer" );
+    if ( !s->committed ) return fail ( kTerraAmdErrNotCommitted, "terra_scene_commit has not run since the scene changed" );
+    if ( !s->device_ok ) return fail ( kTerraAmdErrNoDevice, "scene has no device replica: %s", s->commit_error.c_str() );
+    if ( tile == 0 || tile % 16 != 0 ) return fail ( kTerraAmdErrBadArgument, "tile_size %zu must be a positive multiple of 16", tile );
+    std::lock_guard<std::mutex> lock ( s->multi_lock );
+    const int world = ( int ) s->devices.size();
+    if ( world < 1 || s->extra.size() + 1 != ( size_t ) world ) return fail ( kTerraAmdErrNotCommitted, "the scene's device set changed: commit again" );
+    if ( !s->multi ) { s->multi = new MultiCtx(); s->multi->dev.resize ( ( size_t ) world ); for ( int k = 0; k < world; ++k ) s->multi->dev[ ( size_t ) k].device = s->devices[ ( size_t ) k]; }
+    MultiCtx& m = *s->multi;
+    const size_t npx = w * h;
+    std::vector<size_t> counts ( ( size_t ) world ); size_t total = 0;
+    for ( int k = 0; k < world; ++k ) { counts[ ( size_t ) k] = ( size_t ) tiles_of_rank ( w, h, tile, k, world ) * tile * tile * 7; total += counts[ ( size_t ) k]; }
+    for ( int k = 0; k < world; ++k ) {
+        MultiCtx::PerDevice& q = m.dev[ ( size_t ) k];
+        HIP_TRY ( hipSetDevice ( q.device ), kTerraAmdErrNoDevice );
+        if ( !q.stream ) HIP_TRY ( hipStreamCreateWithFlags ( &q.stream, hipStreamNonBlocking ), kTerraAmdErrNoDevice );
+        if ( q.cap_px < npx ) {
+            if ( q.d_pixels ) ( void ) hipFree ( q.d_pixels );
+            if ( q.d_results ) ( void ) hipFree ( q.d_results );
+            q.d_pixels = q.d_results = nullptr; q.cap_px = 0;
+            HIP_TRY ( hipMalloc ( &q.d_pixels, npx * 12 ), kTerraAmdErrNoDevice ); HIP_TRY ( hipMalloc ( &q.d_results, npx * 16 ), kTerraAmdErrNoDevice );
+            q.cap_px = npx;
+        }
+        if ( q.packed_floats < counts[ ( size_t ) k] ) {
+            if ( q.d_packed ) ( void ) hipFree ( q.d_packed );
+            q.d_packed = nullptr; q.packed_floats = 0;
+            HIP_TRY ( hipMalloc ( ( void** ) &q.d_packed, counts[ ( size_t ) k] * sizeof ( float ) ), kTerraAmdErrNoDevice );
+            q.packed_floats = counts[ ( size_t ) k];
+        }
+        if ( k == 0 && m.recv_floats < total ) {
+            if ( m.d_recv ) ( void ) hipFree ( m.d_recv );
+            m.d_recv = nullptr; m.recv_floats = 0;
+            HIP_TRY ( hipMalloc ( ( void** ) &m.d_recv, total * sizeof ( float ) ), kTerraAmdErrNoDevice );
+            m.recv_floats = total;
+        }
+    }
+    const size_t rpitch = fb->width * 16, ppitch = fb->width * 12;
+    const char* hres = ( const char* ) fb->results + ( y * fb->width + x ) * 16;
+    char* hpix = ( char* ) fb->pixels + ( y * fb->width + x ) * 12;
+    std::vector<DevRenderParams> params ( ( size_t ) world );
+    for ( int k = 0; k < world; ++k ) {          // every device: sums up, its tiles rendered, its tiles packed -- queued on its own stream, nothing waits here
+        MultiCtx::PerDevice& q = m.dev[ ( size_t ) k];
+        HIP_TRY ( hipSetDevice ( q.device ), kTerraAmdErrNoDevice );
+        DevRenderParams& p = params[ ( size_t ) k];
+        if ( int rc = fill_params ( s, cam, fb->width, fb->height, x, y, w, h, tile, k, world, p, k ? &s->extra[ ( size_t ) k - 1] : nullptr ) ) return rc;
+        p.st_x = ( uint32_t ) x; p.st_y = ( uint32_t ) y; p.st_pitch = ( uint32_t ) w;
+        p.pixels = ( float* ) q.d_pixels; p.results = q.d_results; p.rand_calls = nullptr;
+        HIP_TRY ( hipMemcpy2DAsync ( q.d_results, w * 16, hres, rpitch, w * 16, h, hipMemcpyHostToDevice, q.stream ), kTerraAmdErrLaunch );
+        if ( int rc = launch_render ( s, p, q.stream, nullptr, q.device ) ) return rc;
+        HIP_TRY ( terra_launch_tiles ( true, ( float* ) q.d_pixels, q.d_results, ( uint32_t ) w, 0, 0, ( uint32_t ) w, ( uint32_t ) h, ( uint32_t ) tile, ( uint32_t ) k, ( uint32_t ) world, q.d_packed, q.stream ), kTerraAmdErrLaunch );
+    }
+    {   // the one collective
+        std::vector<const float*> send ( ( size_t ) world ); std::vector<hipStream_t> streams ( ( size_t ) world );
+        for ( int k = 0; k < world; ++k ) { send[ ( size_t ) k] = m.dev[ ( size_t ) k].d_packed; streams[ ( size_t ) k] = m.dev[ ( size_t ) k].stream; }
+        std::string err;
+        if ( !multigpu::gather_to_first ( s->devices, send, counts, m.d_recv, streams, err ) ) return fail ( kTerraAmdErrLaunch, "%s", err.c_str() );
+        ++m.gathers; m.last_gather_bytes = total * sizeof ( float );
+    }
+    MultiCtx::PerDevice& q0 = m.dev[0];
+    HIP_TRY ( hipSetDevice ( q0.device ), kTerraAmdErrNoDevice );
+    size_t off = 0;
+    for ( int k = 0; k < world; ++k ) {
+        HIP_TRY ( terra_launch_tiles ( false, ( float* ) q0.d_pixels, q0.d_results, ( uint32_t ) w, 0, 0, ( uint32_t ) w, ( uint32_t ) h, ( uint32_t ) tile, ( uint32_t ) k, ( uint32_t ) world, m.d_recv + off, q0.stream ), kTerraAmdErrLaunch );
+        off += counts[ ( size_t ) k];
+    }
+    HIP_TRY ( hipMemcpy2DAsync ( ( void* ) hres, rpitch, q0.d_results, w * 16, w * 16, h, hipMemcpyDeviceToHost, q0.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipMemcpy2DAsync ( hpix, ppitch, q0.d_pixels, w * 12, w * 12, h, hipMemcpyDeviceToHost, q0.stream ), kTerraAmdErrLaunch );
+    HIP_TRY ( hipStreamSynchronize ( q0.stream ), kTerraAmdErrLaunch );
+    for ( int k = 1; k < world; ++k ) { HIP_TRY ( hipSetDevice ( m.dev[ ( size_t ) k].device ), kTerraAmdErrNoDevice ); HIP_TRY ( hipStreamSynchronize ( m.dev[ ( size_t ) k].stream ), kTerraAmdErrLaunch ); }
+    HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
+    for ( int k = 0; k < world; ++k ) account_launch ( s, params[ ( size_t ) k] );
+    return 0;
+}
+extern "C" int terra_amd_render_multi ( const TerraCamera* cam, HTerraScene h, const TerraFramebuffer* fb, size_t x, size_t y, size_t w, size_t hgt, size_t tile ) {
+    return render_host_multi ( cam, S ( h ), fb, x, y, w, hgt, tile ? tile : 64 );
+}
+extern "C" int terra_amd_multi_info ( HTerraScene h, TerraAmdMultiInfo* out ) {
+    Scene* s = S ( h );
+    if ( !out ) return fail ( kTerraAmdErrBadArgument, "null output" );
+    memset ( out, 0, sizeof *out );
+    out->devices = ( int ) ( s->devices.empty() ? 1 : s->devices.size() );
+    for ( size_t k = 0; k < s->devices.size() && k < 16; ++k ) out->device[k] = s->devices[k];
+    out->replicas = s->device_ok ? ( int ) s->extra.size() + 1 : 0;
+    std::lock_guard<std::mutex> lock ( s->multi_lock );
+    out->gathers = s->multi ? s->multi->gathers : 0; out->last_gather_bytes = s->multi ? s->multi->last_gather_bytes : 0;
+    out->process_collectives = multigpu::collectives_issued(); out->rccl_version = multigpu::rccl_version(); out->communicator_ranks = multigpu::communicator_ranks();
+    snprintf ( out->rccl_library, sizeof out->rccl_library, "%s", multigpu::rccl_path().c_str() );
     return 0;
 }
 

@@ -226,9 +226,6 @@ TD bool moller_trumbore ( V3 o, V3 d, V3 ta, V3 tb, V3 tc, float& t_out, V3& p_o
 // bmin <= bmax, (b - o) * inv is monotone in b (both roundings are), increasing for inv > 0 and decreasing for inv < 0.
 // -----------------------------------------------------------------------------
 #define TERRA_LEAF_CAP_MAX 16
-#ifndef TERRA_ORDERED_LEAVES       // 1: fused launches drain their leaf lists nearest box first, culled by the closest hit (traverse_loops_ordered). Built, bit-identical
-#define TERRA_ORDERED_LEAVES 0     // (all GPU tests), 13 % fewer triangle tests on the Cornell frame -- and 62.9 -> 71.7 ms: its extra live state pushes the 96-register
-#endif                             // kernel into scratch (68 B, reloads inside the ray loop). profiles/r03_measurements/ab_ordered_leaves.log
 #define TERRA_COL 256              // stride of a stack / leaf-list column: the block's thread count
 #define TERRA_LDS_NODE_BYTES 112   // staged node (see above)
 
@@ -388,7 +385,7 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
     sp -= TERRA_COL;
     const uint32_t w = ( uint32_t ) * sp;
     uint32_t child0, child1; bool hit0, hit1;
-    float te0 = 0.f, te1 = 0.f;          // (FUSED) entry distance of each child box
+    float te0 = 0.f, te1 = 0.f;          // (FUSED) entry distance of each child box (unused: kept out of registers by the optimiser)
     if ( MODE == 1 ) {
         const char* node = reinterpret_cast<const char*> ( T.l_nodes ) + w;          // w = byte offset of the staged node
         const uint2 cw = *reinterpret_cast<const uint2*> ( node + 96 );
@@ -421,15 +418,8 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
     const bool leaf0 = ( child0 & DEV_CHILD_LEAF ) != 0, leaf1 = ( child1 & DEV_CHILD_LEAF ) != 0;
     if ( !leaf0 && hit0 ) { TERRA_PUSH ( T, sp, child0 ); }
     if ( !leaf1 && hit1 ) { TERRA_PUSH ( T, sp, child1 ); }
-    if ( FUSED && TERRA_ORDERED_LEAVES ) {
-        // ordered drain (traverse_loops_ordered): an entry = entry distance truncated to its upper 16 bits (never above the true one) | position in the list << 12 | triangle.
-        // Unsigned order of the words = nearest box first, then first met. (Only cull launches come here: a leaf whose box is missed is not listed.)
-        if ( leaf0 && hit0 ) { const uint32_t pos = ( uint32_t ) ( reinterpret_cast<const char*> ( lp ) - reinterpret_cast<const char*> ( T.leaves ) ) << 2; TERRA_LEAF ( T, lp, ( __float_as_uint ( te0 ) & 0xffff0000u ) | pos | ( child0 & 0xfffu ) ); }
-        if ( leaf1 && hit1 ) { const uint32_t pos = ( uint32_t ) ( reinterpret_cast<const char*> ( lp ) - reinterpret_cast<const char*> ( T.leaves ) ) << 2; TERRA_LEAF ( T, lp, ( __float_as_uint ( te1 ) & 0xffff0000u ) | pos | ( child1 & 0xfffu ) ); }
-    } else {
-        if ( leaf0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child0 & 0x7fffffffu ) ); }
-        if ( leaf1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child1 & 0x7fffffffu ) ); }
-    }
+    if ( leaf0 && ( hit0 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child0 & 0x7fffffffu ) ); }
+    if ( leaf1 && ( hit1 || !T.cull ) ) { TERRA_LEAF ( T, lp, ( child1 & 0x7fffffffu ) ); }
     if ( COUNT == 2 && T.cull ) c.tri_culled += ( uint32_t ) ( leaf0 && !hit0 ) + ( uint32_t ) ( leaf1 && !hit1 );
 }
 
@@ -474,54 +464,6 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     }
 }
 
-// Ordered, depth-culled drain of the leaf list -- for the launches whose boxes are covered by the containment proof (Tracer::fused: LDS-resident scene inside the
-// coordinate range, leaf-box cull on). The reference tests every leaf it meets and keeps the smallest depth, the first met among equals (src/TerraBVH.c:284-300).
-// A triangle's hit lies at least its box margin (1e-4, against ~1e-6 of rounding: the proof's budget) beyond the point where the ray enters that triangle's box,
-// so a leaf whose box is entered BEYOND the closest hit found so far cannot change the answer. Per drain: (1) the entry with the nearest box is tested first --
-// one test per lane, all lanes that hold a leaf together; (2) the list is compacted to the entries whose box is entered no later than that hit; (3) those are
-// tested. On the Cornell frame a ray through one of the boxes lists 6 leaves (entry face, exit face, the wall behind: two triangles each) and now tests 2.
-// Ties in depth go to the entry met first, as in the reference: every entry carries its position in the visit order.
-template <int COUNT>
-TD void leaf_step_packed ( const Tracer& T, uint32_t word, uint32_t drain, const RayState& st, V3 o_perm, Closest& best, uint32_t& best_vis, Counters& c ) {
-    PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
-    const uint32_t ti = word & 0xfffu, vis = ( drain << 4 ) | ( ( word >> 12 ) & 15u );
-    const int kx = st.ix, ky = st.iy, kz = st.iz;
-    const float* t = T.l_tris + 12 * ti;
-    float pa[3], pb[3], pc[3];
-    pa[0] = t[kx]; pa[1] = t[ky]; pa[2] = t[kz];
-    pb[0] = t[4 + kx]; pb[1] = t[4 + ky]; pb[2] = t[4 + kz];
-    pc[0] = t[8 + kx]; pc[1] = t[8 + ky]; pc[2] = t[8 + kz];
-    if ( COUNT ) ++c.tri_tests;
-    float depth;
-    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && ( depth < best.depth || ( depth == best.depth && vis < best_vis ) ) ) { best.depth = depth; best.tri = ti; best_vis = vis; }
-}
-template <int COUNT>
-TD void traverse_loops_ordered ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
-    const SlabSel sel = slab_sel ( r );
-    int* sp = T.stack; int* lp = T.leaves;
-    int* const lp_full = T.leaves + ( T.leaf_cap - 2 ) * TERRA_COL;       // a node adds at most two leaves
-    *sp = 0; sp += TERRA_COL;
-    uint32_t best_vis = 0xffffffffu, drain = 0;
-    for ( ;; ) {
-        PS_WAVE ( c, kPsDrainIter );
-        while ( sp != T.stack && lp <= lp_full ) node_step<COUNT, 1, true, true> ( T, r, sel, sp, lp, c );
-        if ( lp != T.leaves ) {
-            uint32_t nearest = 0xffffffffu;
-            for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) { const uint32_t w = ( uint32_t ) * e; nearest = w < nearest ? w : nearest; }
-            leaf_step_packed<COUNT> ( T, nearest, drain, st, o_perm, best, best_vis, c );
-            int* keep = T.leaves;
-            for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) {
-                const uint32_t w = ( uint32_t ) * e;
-                if ( w != nearest && __uint_as_float ( w & 0xffff0000u ) <= best.depth ) { *keep = ( int ) w; keep += TERRA_COL; }
-                else if ( COUNT == 2 && w != nearest ) ++c.tri_culled;
-            }
-            for ( const int* e = T.leaves; e != keep; e += TERRA_COL ) leaf_step_packed<COUNT> ( T, ( uint32_t ) * e, drain, st, o_perm, best, best_vis, c );
-            lp = T.leaves; ++drain;
-        }
-        if ( sp == T.stack ) break;
-    }
-}
-
 template <int COUNT, int MODE>
 TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
     Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
@@ -530,10 +472,7 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 #ifndef TERRA_FUSED_SLAB
 #define TERRA_FUSED_SLAB 1
 #endif
-    if ( TERRA_FUSED_SLAB && MODE == 1 && T.fused && __all ( ray_is_tame ( r ) ) ) {
-        if ( TERRA_ORDERED_LEAVES ) traverse_loops_ordered<COUNT> ( T, r, st, o_perm, best, c );
-        else traverse_loops<COUNT, MODE, true, true> ( T, r, st, o_perm, best, c );
-    }
+    if ( TERRA_FUSED_SLAB && MODE == 1 && T.fused && __all ( ray_is_tame ( r ) ) ) traverse_loops<COUNT, MODE, true, true> ( T, r, st, o_perm, best, c );
     else if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true> ( T, r, st, o_perm, best, c );
     else traverse_loops<COUNT, MODE, false> ( T, r, st, o_perm, best, c );
     return best;
@@ -547,19 +486,41 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 // leaf visit order resolves them: smallest depth, then smallest reference visit rank
 // (DevTri::pad of the fast soup). The triangle test itself is the same arithmetic.
 // Child word of a fast node: bit 31 leaf; leaf = (count-1) << 27 | first triangle.
-// -----------------------------------------------------------------------------
-// Entry distance of a fast-tree box, stored as (centre, half extent) (tree_build_device.hip "Traversal form"). Unlike the
+//
+// Node format in HBM (DevFastNode, 64 B = half a cache line; written in place over the builder's (min, max) node by
+// tree_build_device.hip tb_half_planes_kernel): the twelve planes of the two child boxes as binary16, rounded OUTWARD, stored
+// axis major and for BOTH ray signs --
+//     [x+] min0 max0 min1 max1   [x-] max0 min0 max1 min1   [y+] ..  [y-] ..  [z+] ..  [z-] ..   child0 child1  (8 B spare)
+// A ray reads, per axis, the 8-byte quad that matches the sign of its direction: the four halves are then (near, far) of child 0
+// and of child 1, no per-axis min / max and no select; each plane goes straight into t = fma ( plane, inv, -(o * inv) ) as the
+// binary16 operand of v_fma_mix_f32, so a box costs six fused multiply-adds, a v_max3, a v_min3 and the comparisons. Unlike the
 // reference tree's test this one only has to be CONSERVATIVE (never reject a box that holds a triangle the ray hits; DESIGN.md
-// "Traversal policy"): near / far per axis come out of one subtraction and one addition, v_max3 / v_min3 drop a NaN (0 x inf or
-// inf - inf: a ray parallel to a box plane), which only widens the interval.
-TD bool slab_enter ( V3 c, V3 h, const Ray& r, float& t_enter ) {
-    const float tcx = ( c.x - r.o.x ) * r.inv.x, hx = h.x * __builtin_fabsf ( r.inv.x );
-    const float tcy = ( c.y - r.o.y ) * r.inv.y, hy = h.y * __builtin_fabsf ( r.inv.y );
-    const float tcz = ( c.z - r.o.z ) * r.inv.z, hz = h.z * __builtin_fabsf ( r.inv.z );
-    const float tmin = __builtin_fmaxf ( __builtin_fmaxf ( tcx - hx, tcy - hy ), tcz - hz );
-    const float tmax = __builtin_fminf ( __builtin_fminf ( tcx + hx, tcy + hy ), tcz + hz );
-    t_enter = __builtin_fmaxf ( tmin, 0.f );
-    return tmax > t_enter;
+// "Traversal policy"): rounding the planes outward only widens the box, and t carries two roundings (o * inv, the fma) where the
+// commit-time error budget (scene_host.cpp "numeric containment check") allows four. Planes are stored times DevScene::fast_scale
+// (a power of two: exact) so that every scene fits binary16's range; the ray's inverse direction is divided by it (exact too).
+// An empty child slot is an inverted box (min = +max_half, max = -max_half): never entered, so no lane ever holds it.
+// -----------------------------------------------------------------------------
+typedef _Float16 terra_half2 __attribute__ (( ext_vector_type ( 2 ) ));
+TD terra_half2 as_half2 ( uint32_t u ) { return __builtin_bit_cast ( terra_half2, u ); }
+// what a ray needs of itself for the fast tree's box test: the inverse direction -- clamped (a ray parallel to an axis has an infinite inverse direction there, and inf - inf
+// would drop that axis from the test: correct but ruinous, such a ray then visits every box along its line; clamped to +-2^100 the axis keeps its meaning: (plane - o) * 2^100
+// has the sign of "outside the slab") and divided by the planes' scale --, origin x clamped inverse direction, and the byte offset of the quad each axis reads
+struct FastRay { V3 inv, oi; uint32_t sx, sy, sz; };
+TD FastRay fast_ray ( const Ray& ray, float inv_scale ) {
+    FastRay f;
+    const float cx = __builtin_fminf ( __builtin_fmaxf ( ray.inv.x, -0x1p100f ), 0x1p100f ), cy = __builtin_fminf ( __builtin_fmaxf ( ray.inv.y, -0x1p100f ), 0x1p100f ), cz = __builtin_fminf ( __builtin_fmaxf ( ray.inv.z, -0x1p100f ), 0x1p100f );
+    f.oi = v3 ( ray.o.x * cx, ray.o.y * cy, ray.o.z * cz );
+    f.inv = v3 ( cx * inv_scale, cy * inv_scale, cz * inv_scale );
+    f.sx = cx < 0.f ? 8u : 0u; f.sy = cy < 0.f ? 24u : 16u; f.sz = cz < 0.f ? 40u : 32u;
+    return f;
+}
+// entry distance of one child box from its (near, far) planes per axis; hit = the ray's interval inside the box is not empty
+TD bool slab_half ( _Float16 nx, _Float16 fx, _Float16 ny, _Float16 fy, _Float16 nz, _Float16 fz, const FastRay& f, float& t_enter ) {
+    const float tnx = __builtin_fmaf ( ( float ) nx, f.inv.x, -f.oi.x ), tfx = __builtin_fmaf ( ( float ) fx, f.inv.x, -f.oi.x );
+    const float tny = __builtin_fmaf ( ( float ) ny, f.inv.y, -f.oi.y ), tfy = __builtin_fmaf ( ( float ) fy, f.inv.y, -f.oi.y );
+    const float tnz = __builtin_fmaf ( ( float ) nz, f.inv.z, -f.oi.z ), tfz = __builtin_fmaf ( ( float ) fz, f.inv.z, -f.oi.z );
+    t_enter = __builtin_fmaxf ( __builtin_fmaxf ( __builtin_fmaxf ( tnx, tny ), tnz ), 0.f );
+    return __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz ) > t_enter;
 }
 
 struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
@@ -594,11 +555,12 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
     return ok;
 }
 
-// Leaves are pushed on the stack like inner nodes (near child last, so it is popped first). A lane that pops a leaf
-// HOLDS it; each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and
-// some lane can still descend) the descending lanes take a node step, otherwise the holders test one triangle each.
-// (16/16 is the classic "while-while" loop: descend until every lane holds a leaf.) The vote trades a fuller node step --
-// 6 x more executions than triangle steps on the hall -- against an emptier triangle step.
+// The far child of a node whose two boxes are hit waits on the lane's stack (LDS); the near one stays in a register (`cur`) --
+// or, when it is a leaf, goes straight into `leaf`: a lane that has a leaf in hand HOLDS it. Each iteration the wave votes: while
+// fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and some lane can still descend) the descending lanes take
+// a node step, otherwise the holders test one triangle each. (16/16 is the classic "while-while" loop: descend until every lane
+// holds a leaf.) The vote trades a fuller node step -- 6 x more executions than triangle steps on the hall -- against an emptier
+// triangle step.
 // The traversal is resumable (stack column in LDS; top, held leaf, closest hit in registers): it returns as soon as the
 // number of lanes still traversing has dropped to `exit_active`, so the render loop can shade the finished lanes and hand
 // them their next ray (exit_active = 0: run every lane's ray to the end). `traversing` is cleared for lanes whose traversal
@@ -606,33 +568,20 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 #ifndef TERRA_FAST_LEAF_16THS
 #define TERRA_FAST_LEAF_16THS 8
 #endif
-#ifndef TERRA_PROBE_VMEM
-#define TERRA_PROBE_VMEM 0
-#endif
-#ifndef TERRA_PROBE_VALU
-#define TERRA_PROBE_VALU 0
-#endif
-#ifndef TERRA_FAST_PREFIX_MODE     // how a node of the fast tree is fetched: 1 = one flat load from the staged prefix (LDS) or global memory; 0 / 2: A/B forms below
-#define TERRA_FAST_PREFIX_MODE 1
-#endif
 template <int COUNT>
 TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c, bool checked = false ) {
-    // a ray parallel to an axis has an infinite inverse direction there, and inf - inf would drop that axis from the test:
-    // correct but ruinous (such a ray then visits every box along its line; one lane walking 20k nodes alone costs tens of
-    // milliseconds). Clamped to +-2^100 the axis keeps its meaning: (|c - o| - h) * 2^100 has the sign of "outside the slab".
-    Ray r = ray;
-    r.inv.x = __builtin_fminf ( __builtin_fmaxf ( r.inv.x, -0x1p100f ), 0x1p100f );
-    r.inv.y = __builtin_fminf ( __builtin_fmaxf ( r.inv.y, -0x1p100f ), 0x1p100f );
-    r.inv.z = __builtin_fminf ( __builtin_fmaxf ( r.inv.z, -0x1p100f ), 0x1p100f );
-    const float4* nodes = reinterpret_cast<const float4*> ( T.sc.fast_nodes );
-    const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
+    const FastRay f = fast_ray ( ray, T.sc.fast_inv_scale );
+    const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes );
+    const char* tris = reinterpret_cast<const char*> ( T.sc.fast_tris );
+    // the vertex components the triangle test reads, as byte offsets inside a 48-byte triangle: the ray's (kx, ky, kz) axes select the ADDRESS, not the loaded value
+    const uint32_t kx4 = ( uint32_t ) st.ix << 2, ky4 = ( uint32_t ) st.iy << 2, kz4 = ( uint32_t ) st.iz << 2;
     // `cur`: the node a lane descends into next stays in a register (the near child when both are hit); only the far child
     // goes through the stack, so a descent step does not wait for an LDS write + read of its own
     uint32_t cur = DEV_CHILD_EMPTY;
     for ( ;; ) {
         const bool holder = traversing && leaf != 0;
         const bool can = traversing && leaf == 0 && ( cur != DEV_CHILD_EMPTY || top != T.stack );
-        const int n_can = __popcll ( __ballot ( can ) ), n_hold = __popcll ( __ballot ( holder ) );
+        const int n_can = __popcll ( __builtin_amdgcn_ballot_w64 ( can ) ), n_hold = __popcll ( __builtin_amdgcn_ballot_w64 ( holder ) );
         traversing = can || holder;                                  // a lane with nothing in hand and an empty stack is done
         if ( n_can + n_hold <= exit_active ) break;
         if ( n_can != 0 && n_hold * 16 < ( n_can + n_hold ) * TERRA_FAST_LEAF_16THS ) {
@@ -641,59 +590,43 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
                 uint32_t w = cur;
                 if ( w == DEV_CHILD_EMPTY ) { top -= TERRA_COL; w = ( uint32_t ) * top; }
                 cur = DEV_CHILD_EMPTY;
-                if ( w & DEV_CHILD_LEAF ) leaf = w;
+                if ( w & DEV_CHILD_LEAF ) leaf = w;                  // (a far child that was a leaf comes off the stack)
                 else {
-#if TERRA_FAST_PREFIX_MODE == 0          // (A/B) no staged prefix: plain global loads
-                    float4 q0 = nodes[4 * w], q1 = nodes[4 * w + 1], q2 = nodes[4 * w + 2], q3 = nodes[4 * w + 3];
-#elif TERRA_FAST_PREFIX_MODE == 2        // (A/B) the staged prefix behind a branch: ds_read or global_load instead of flat_load
-                    float4 q0, q1, q2, q3;
-                    if ( w < T.lds_nodes ) { const float4* ls = T.l_nodes + 4 * w; q0 = ls[0]; q1 = ls[1]; q2 = ls[2]; q3 = ls[3]; }
-                    else { const float4* gs = nodes + 4 * ( size_t ) w; q0 = gs[0]; q1 = gs[1]; q2 = gs[2]; q3 = gs[3]; }
-#else
-                    const float4* nsrc = w < T.lds_nodes ? T.l_nodes : nodes;            // the staged prefix (LDS) or the array in global memory: same 64-B layout (one flat load serves both)
-                    float4 q0 = nsrc[4 * w], q1 = nsrc[4 * w + 1], q2 = nsrc[4 * w + 2], q3 = nsrc[4 * w + 3];
-#endif
-                    uint32_t child0 = __float_as_uint ( q3.x ), child1 = __float_as_uint ( q3.y );
+                    const uint32_t off = w << 6;
+                    const uint2 qx = *reinterpret_cast<const uint2*> ( nodes + ( off + f.sx ) ), qy = *reinterpret_cast<const uint2*> ( nodes + ( off + f.sy ) ), qz = *reinterpret_cast<const uint2*> ( nodes + ( off + f.sz ) );
+                    const uint2 ch = *reinterpret_cast<const uint2*> ( nodes + ( off + 48u ) );
                     if ( COUNT ) ++c.nodes;
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
-#if TERRA_PROBE_VMEM          // (sensitivity probe, measurement builds only) one more 16-byte request per node step: 1 = the neighbouring node (same 128-B line), 2 = a node far away
-                    { const uint32_t w2 = TERRA_PROBE_VMEM == 1 ? ( w ^ 1u ) : ( w * 7919u + 13u ) % T.sc.n_fast_nodes; const float4 x = nodes[4 * ( size_t ) w2]; asm volatile ( "" :: "v" ( x.x ) ); }
-#endif
-#if TERRA_PROBE_VALU          // (sensitivity probe) this many extra dependent v_fma_f32 per node step
-                    { float dummy = q0.x;
-                      #pragma unroll
-                      for ( int k = 0; k < TERRA_PROBE_VALU; ++k ) asm volatile ( "v_fma_f32 %0, %0, %0, %0" : "+v" ( dummy ) );
-                      asm volatile ( "" :: "v" ( dummy ) ); }
-#endif
+                    const terra_half2 x0 = as_half2 ( qx.x ), x1 = as_half2 ( qx.y ), y0 = as_half2 ( qy.x ), y1 = as_half2 ( qy.y ), z0 = as_half2 ( qz.x ), z1 = as_half2 ( qz.y );
                     float te0, te1;
-                    bool hit0 = slab_enter ( v3 ( q0.x, q0.y, q0.z ), v3 ( q0.w, q1.x, q1.y ), r, te0 ) && te0 <= best.depth && child0 != DEV_CHILD_EMPTY;
-                    bool hit1 = slab_enter ( v3 ( q1.z, q1.w, q2.x ), v3 ( q2.y, q2.z, q2.w ), r, te1 ) && te1 <= best.depth && child1 != DEV_CHILD_EMPTY;
+                    const bool hit0 = slab_half ( x0.x, x0.y, y0.x, y0.y, z0.x, z0.y, f, te0 ) && te0 <= best.depth;
+                    const bool hit1 = slab_half ( x1.x, x1.y, y1.x, y1.y, z1.x, z1.y, f, te1 ) && te1 <= best.depth;
+                    const bool one_near = hit1 && ! ( hit0 && te0 <= te1 );          // child 1 is the one to enter first
+                    const uint32_t near = one_near ? ch.y : ch.x, far = one_near ? ch.x : ch.y;
                     if ( hit0 && hit1 ) {
-                        bool zero_near = te0 <= te1;
-                        TERRA_PUSH ( T, top, ( zero_near ? child1 : child0 ) );
+                        TERRA_PUSH ( T, top, far );
 #if TERRA_PHASE_STATS
                         { const int dpt = ( int ) ( top - T.stack ) / TERRA_COL; ++c.ps[kPsCamLanes]; c.ps[kPsShadeIter] += dpt >= 4; c.ps[kPsRayLanes] += dpt >= 6; c.ps[kPsCamIter] += dpt >= 8; c.ps[kPsDrainIter] += dpt >= 10; c.ps[kPsShadeLanes] += dpt >= 12; }
 #endif
-                        cur = zero_near ? child0 : child1;
-                    } else if ( hit0 ) cur = child0;
-                    else if ( hit1 ) cur = child1;
+                    }
+                    if ( hit0 || hit1 ) { if ( near & DEV_CHILD_LEAF ) leaf = near; else cur = near; }
                 }
             }
         } else if ( holder ) {
             PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
             const uint32_t ti = leaf & 0x07ffffffu;
             leaf = ( leaf & 0x78000000u ) ? leaf + 1u - 0x08000000u : 0u;        // next triangle of the leaf, one fewer to go; 0 = nothing in hand
-            float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];
-            V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
-            float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
-            float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
-            float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
+            const uint32_t t48 = ti * 48u;
+            const char* ta = tris + ( t48 + kx4 ); const char* tb = tris + ( t48 + ky4 ); const char* tc = tris + ( t48 + kz4 );
+            const float pa[3] = { *reinterpret_cast<const float*> ( ta ), *reinterpret_cast<const float*> ( tb ), *reinterpret_cast<const float*> ( tc ) };
+            const float pb[3] = { *reinterpret_cast<const float*> ( ta + 16 ), *reinterpret_cast<const float*> ( tb + 16 ), *reinterpret_cast<const float*> ( tc + 16 ) };
+            const float pc[3] = { *reinterpret_cast<const float*> ( ta + 32 ), *reinterpret_cast<const float*> ( tb + 32 ), *reinterpret_cast<const float*> ( tc + 32 ) };
+            const uint32_t rank = *reinterpret_cast<const uint32_t*> ( tris + ( t48 + 44u ) );
             if ( COUNT ) ++c.tri_tests;
             float depth;
             if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
-                uint32_t rank = __float_as_uint ( cc.w );
                 if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) {
                     if ( !checked || reference_reaches ( T, ti, ray ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }      // (checked: DevScene::reach, second pass)
                 }

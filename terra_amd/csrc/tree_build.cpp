@@ -125,7 +125,7 @@ void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nod
 // ---- fast tree: 3-axis binned SAH, BVH2, leaves of <= 4 triangles ----------
 // Built over the same per-triangle boxes as the reference (triangle bounds +- 1e-4) so every
 // triangle a ray can hit lies inside its ancestors' boxes; inner boxes are plain unions.
-#ifndef TERRA_FAST_PREFIX_NODES  // nodes of the fast tree's top levels numbered first (and staged in LDS by the MODE 2 kernel; render_kernels.hip)
+#ifndef TERRA_FAST_PREFIX_NODES  // nodes of the fast tree's top levels numbered first: the levels every ray visits share a few cache lines
 #define TERRA_FAST_PREFIX_NODES 64
 #endif
 #ifndef TERRA_FAST_LEAF_MAX      // triangles per leaf of the fast tree (the leaf word holds count-1 in 4 bits)
@@ -321,8 +321,7 @@ Built build ( std::vector<Prim>& prims ) {
         // ordered traversal with the near child kept in a register: one pending (far) child per level, plus the node in hand when a lane leaves the loop
         out.max_stack = max_depth + 1;
     }
-    // Numbering: the first TERRA_FAST_PREFIX_NODES nodes in breadth-first order (the levels every ray visits: the kernel stages them
-    // in LDS), all others depth first (a node is followed by one child's whole subtree: a descent finds its next
+    // Numbering: the first TERRA_FAST_PREFIX_NODES nodes in breadth-first order (the levels every ray visits, packed into 4 KB), all others depth first (a node is followed by one child's whole subtree: a descent finds its next
     // nodes close by; measured on the 97k-triangle hall, a fully breadth-first array renders 3.7 % slower).
     {
         const size_t K = std::min ( out.nodes.size(), ( size_t ) TERRA_FAST_PREFIX_NODES );

@@ -217,31 +217,50 @@ hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* ra
 }
 
 // -----------------------------------------------------------------------------
-// Traversal form of a fast-tree node: each child box (min, max) becomes (centre, half extent), same 24 bytes, so that the
-// slab test needs no per-axis min / max:  t_near = (c - o) * inv - h * |inv|,  t_far = (c - o) * inv + h * |inv|  -- five
-// full-rate instructions per axis instead of four plus two half-rate ones (profiles/r02_measurements/valu_rates.log).
-// The new box CONTAINS the old one (h is rounded up from a double-precision difference), which is all the fast tree's
-// traversal needs (DESIGN.md "Traversal policy"); the commit-time containment check runs on the (min, max) boxes before this.
+// Traversal form of a fast-tree node (dev_types.h DevFastNode; the traversal is trace_device.h traverse_fast_resume): each child
+// box (min, max) becomes six binary16 planes, times `scale` (a power of two chosen by the host so that every plane fits binary16's
+// range), rounded OUTWARD -- min down, max up -- and stored for both ray signs. The new box CONTAINS the old one, which is all the
+// fast tree's traversal needs (DESIGN.md "Traversal policy"); the commit-time containment check runs on the (min, max) boxes before
+// this. Written in place: a thread reads its node's 64 bytes, then writes 64 bytes.
 // -----------------------------------------------------------------------------
-__global__ __launch_bounds__ ( 256 ) void tb_center_extent_kernel ( DevNode* nodes, uint32_t n ) {
+// x -> the largest binary16 <= x (DOWN) or the smallest >= x (up), as bits. HIP's __float2half_rd / _ru are not relied upon (their rounding is not
+// pinned across ROCm releases): round to nearest, then step one binary16 towards the wanted side if that went the wrong way. +-inf results are fine (wider).
+template <bool DOWN>
+__device__ __forceinline__ uint16_t half_outward ( double x ) {      // (a double: plane x scale is exact in it whatever the scale)
+    const _Float16 h = ( _Float16 ) ( float ) x;
+    uint16_t u = __builtin_bit_cast ( uint16_t, h );
+    const double b = ( double ) ( float ) h;
+    if ( DOWN ? b > x : b < x ) {
+        const bool away = DOWN ? ( u & 0x8000u ) != 0 : ( u & 0x8000u ) == 0;      // the step goes away from zero: one more in magnitude
+        if ( ( u & 0x7fffu ) == 0 ) u = DOWN ? 0x8001u : 0x0001u;                   // from +-0 to the smallest subnormal of the wanted sign
+        else u = away ? u + 1u : u - 1u;
+    }
+    return u;
+}
+__global__ __launch_bounds__ ( 256 ) void tb_half_planes_kernel ( DevNode* nodes, uint32_t n, float scale ) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if ( i >= 2 * n ) return;
-    DevNode& nd = nodes[i >> 1];
-    float* mn = ( i & 1 ) ? nd.min1 : nd.min0; float* mx = ( i & 1 ) ? nd.max1 : nd.max0;
+    if ( i >= n ) return;
+    const DevNode nd = nodes[i];
+    DevFastNode out;
     #pragma unroll
     for ( int a = 0; a < 3; ++a ) {
-        const float lo = mn[a], hi = mx[a];
-        const float c = 0.5f * ( lo + hi );
-        const double hd = fmax ( ( double ) c - ( double ) lo, ( double ) hi - ( double ) c );
-        float h = ( float ) hd;
-        if ( ( double ) h < hd ) h = __uint_as_float ( __float_as_uint ( h ) + 1u );      // round up (h >= 0 here)
-        if ( !( lo <= hi ) ) h = -1.f;                                                      // an empty box stays empty
-        mn[a] = c; mx[a] = h;
+        uint16_t lo[2], hi[2];
+        #pragma unroll
+        for ( int k = 0; k < 2; ++k ) {
+            const float mn = ( k ? nd.min1 : nd.min0 ) [a], mx = ( k ? nd.max1 : nd.max0 ) [a];
+            const bool empty = nd.child[k] == DEV_CHILD_EMPTY || !( mn <= mx );
+            lo[k] = empty ? ( uint16_t ) 0x7bffu : half_outward<true> ( ( double ) mn * ( double ) scale );      // an empty slot: min = +65504, max = -65504 -- no ray enters it
+            hi[k] = empty ? ( uint16_t ) 0xfbffu : half_outward<false> ( ( double ) mx * ( double ) scale );
+        }
+        out.q[2 * a][0] = lo[0]; out.q[2 * a][1] = hi[0]; out.q[2 * a][2] = lo[1]; out.q[2 * a][3] = hi[1];
+        out.q[2 * a + 1][0] = hi[0]; out.q[2 * a + 1][1] = lo[0]; out.q[2 * a + 1][2] = hi[1]; out.q[2 * a + 1][3] = lo[1];
     }
+    out.child[0] = nd.child[0]; out.child[1] = nd.child[1]; out.spare[0] = 0; out.spare[1] = 0;
+    *reinterpret_cast<DevFastNode*> ( &nodes[i] ) = out;
 }
-hipError_t terra_fast_nodes_center_extent ( DevNode* nodes, uint32_t n, hipStream_t stream ) {
+hipError_t terra_fast_nodes_half_planes ( DevNode* nodes, uint32_t n, float scale, hipStream_t stream ) {
     if ( n == 0 ) return hipSuccess;
-    hipLaunchKernelGGL ( tb_center_extent_kernel, dim3 ( ( 2 * n + 255 ) / 256 ), dim3 ( 256 ), 0, stream, nodes, n );
+    hipLaunchKernelGGL ( tb_half_planes_kernel, dim3 ( ( n + 255 ) / 256 ), dim3 ( 256 ), 0, stream, nodes, n, scale );
     hipError_t e = hipGetLastError();
     return e != hipSuccess ? e : hipStreamSynchronize ( stream );
 }

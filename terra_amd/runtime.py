@@ -65,6 +65,12 @@ _EXTRA = {
     "terra_amd_get_device": (C.c_int, []),
     "terra_amd_set_frame_seed": (None, [C.c_void_p, C.c_uint64]),
     "terra_amd_debug_shrink_reference_boxes": (C.c_int, [C.c_void_p, C.c_float]),
+    "terra_amd_debug_pad_stack": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "terra_amd_get_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "terra_amd_shard_owner": (C.c_int, [C.c_size_t, C.c_int]),
+    "terra_amd_render_multi": (C.c_int, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 5),
+    "terra_amd_multi_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "terra_amd_set_work_counters": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_work_counters": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sampler_integration": (C.c_int, [C.c_void_p, C.c_int]),
@@ -129,6 +135,12 @@ def first_error():
     buf = C.create_string_buffer(512)
     st = load().first_error(buf, 512)
     return st, buf.value.decode()
+
+
+class MultiInfo(C.Structure):
+    """TerraAmdMultiInfo (include/terra_amd.h)"""
+    _fields_ = [("devices", C.c_int), ("device", C.c_int * 16), ("replicas", C.c_int), ("gathers", C.c_uint64), ("last_gather_bytes", C.c_uint64),
+                ("process_collectives", C.c_uint64), ("rccl_version", C.c_int), ("communicator_ranks", C.c_int), ("rccl_library", C.c_char * 64)]
 
 
 class DeviceFramebuffer:

@@ -744,3 +744,54 @@ def test_decoupled_loop_matches_the_oracle(H, L, orc_lib, devmath_mode, name, in
     info = runtime.SceneInfo(); runtime.check(L.scene_info(scene, C.byref(info)))
     L.scene_destroy(scene)
     assert info.triangles > 300, "must be a scene the LDS plan does not stage whole"
+
+
+# ---------------------------------------------------------------------------
+# a traversal stack deeper than 64 KB of LDS per block (render_kernels.hip launch_instance opts in; terra_plan_lds clamps the leaf list). The reference's own builder
+# only produces such stacks on inputs of pathological size, so the launches are driven through the test hook terra_amd_debug_pad_stack on an ordinary scene.
+# ---------------------------------------------------------------------------
+
+def _padded_render(L, d, mode, pad):
+    scene = scenes.build_scene(L, d, tree_mode=mode)
+    runtime.check(L.debug_pad_stack(scene, pad))
+    fb = runtime.DeviceFramebuffer(d.width, d.height)
+    L.clear_error()
+    rc = L.render_device(C.byref(scenes.camera_of(d)), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, None)
+    import torch
+    torch.cuda.synchronize()
+    out = dict(rc=rc, err=runtime.last_error(), pixels=fb.pixels_host().copy(), acc=fb.results_host()["acc"].copy())
+    L.clear_error(); L.scene_destroy(scene)
+    return out
+
+
+@pytest.mark.parametrize("integ", [0, 1])
+def test_a_stack_deeper_than_64_kb_of_lds_renders(H, L, orc_lib, devmath_mode, integ):
+    from test_oracle_vs_reference import soup_scene
+    d = soup_scene(H, 1500, 77, integrator=integ); d.width, d.height, d.spp = 64, 40, 2          # not LDS-resident: reference tree from global memory / fast tree
+    want = H.Unit("orc").render_pixels(d)
+    for mode in (0, 2):
+        for pad in (0, 60, 110):             # 60: the block asks for more than 64 KB (replica: stack + a 4-entry leaf list + parked rows); 110: ~130 KB, one block per CU
+            got = _padded_render(L, d, mode, pad)
+            assert got["rc"] == 0 and got["err"] == "", (mode, pad, got["err"])
+            assert same(H, got["pixels"], want["pixels"]) and same(H, got["acc"], want["acc"]), (mode, pad)
+    got = _padded_render(L, d, 0, 400)         # beyond what a block can hold: refused with a message, nothing launched, nothing rendered
+    assert got["rc"] < 0 and "LDS per block" in got["err"] and not got["acc"].any()
+
+
+def test_note_and_last_call_agree(H, L):
+    """whatever the commit decided and the note says, terra_amd_traversal_info's flags and last_call name the traversal a render actually runs"""
+    from test_oracle_vs_reference import soup_scene
+    big = soup_scene(H, 1500, 78); big.width, big.height, big.spp = 32, 24, 1
+    for d, mode in ((big, 2), (big, 0), (big, 1), (scenes.cornell_box(32, 24, 1), 2), (scenes.cornell_box(32, 24, 1), 0), (scenes.cornell_spheres(32, 24, 1), 2)):
+        scene = scenes.build_scene(L, d, tree_mode=mode)
+        fb = runtime.DeviceFramebuffer(d.width, d.height)
+        runtime.render_device(L, scenes.camera_of(d), scene, fb)
+        ti = runtime.TraversalInfo(); runtime.check(L.traversal_info(scene, C.byref(ti)))
+        note = ti.note.decode(); name = runtime.CALL_TRAVERSAL[ti.last_call]
+        if ti.fast_tree:
+            assert "fast tree" in note and name.startswith("fast tree"), (note, name)
+        elif ti.leaf_cull:
+            assert "leaf-box cull" in note and name == "reference tree + leaf-box cull", (note, name)
+        else:
+            assert "replica" in note and name == "reference tree, replica traversal", (note, name)
+        L.scene_destroy(scene)
