@@ -80,6 +80,13 @@ typedef struct {
 } TerraAmdMultiInfo;
 int  terra_amd_multi_info ( HTerraScene scene, TerraAmdMultiInfo* out );
 
+/* Can this library render the scene as it stands (objects added, options set; before or after terra_scene_commit)? 0 = yes; otherwise the TerraAmdStatus the commit
+   would record, with the reason in `why` (capacity bytes, always terminated; may be NULL). The reference runs any host callback a material carries
+   (TerraBSDF::sample / pdf / eval, TerraAttribute::eval: src/Terra.c:1071-1075, 1804-1810); the device runs the presets of TerraPresets.h and texture lookups only, and
+   this library has no CPU path: a client that supports custom callbacks asks here first and keeps such scenes on the reference renderer. A pure query: nothing is
+   recorded in the error channels. */
+int  terra_amd_scene_supported ( HTerraScene scene, char* why, size_t capacity );
+
 /* Frame seed F of the per-pixel random streams (DESIGN.md "Randomness"):
    replaces the reference's time(NULL)^&exit seed (src/Terra.c:679) and libc
    rand() (src/Terra.c:115). Default 0x5EED0001. */

@@ -38,15 +38,14 @@ struct DevNode {
 };
 static_assert ( sizeof ( DevNode ) == 64, "DevNode must be 64 bytes" );
 
-// A fast-tree node as the kernels read it (trace_device.h "MODE 2"): the planes of the two child boxes as binary16 rounded outward, times DevScene's
-// power-of-two scale, axis major and for both ray signs: q[2 * axis + 0] = { min0, max0, min1, max1 }, q[2 * axis + 1] = { max0, min0, max1, min1 };
-// child words as in DevNode (inner: node index; leaf: DEV_CHILD_LEAF | (count - 1) << 27 | first triangle); an empty slot is an inverted box.
+// A fast-tree node as the kernels read it (trace_device.h "MODE 2"), 32 bytes = two 16-byte loads: per child and axis the two planes of the child's box as binary16
+// rounded outward (min down, max up), times DevScene's power-of-two scale -- p[child][axis] = min | max << 16 --, then the child words as in DevNode (inner: node
+// index; leaf: DEV_CHILD_LEAF | (count - 1) << 27 | first triangle). An empty slot is an inverted box (min = +65504, max = -65504).
 struct DevFastNode {
-    uint16_t q[6][4];
+    uint32_t p[2][3];
     uint32_t child[2];
-    uint32_t spare[2];
 };
-static_assert ( sizeof ( DevFastNode ) == 64, "DevFastNode must be 64 bytes" );
+static_assert ( sizeof ( DevFastNode ) == 32, "DevFastNode must be 32 bytes" );
 
 struct DevTri {
     float    a[3]; uint32_t object;
@@ -116,7 +115,8 @@ struct DevScene {
     // optional second accelerator over the same triangles (terra_amd_set_tree_mode, DESIGN.md "Fast tree"):
     // 3-axis binned-SAH BVH2, leaves of up to 4 triangles; fast_tris is the soup in leaf order with
     // DevTri::pad = the triangle's rank in the REFERENCE tree's leaf visit order (the tie-break key)
-    const DevNode*     fast_nodes;      // built as DevNode (min, max), then rewritten in place as DevFastNode: that is what the kernels traverse
+    const DevNode*     fast_nodes;      // as built: (min, max) boxes, 64 B (what the containment check reads; the kernels do not)
+    const DevFastNode* fast_nodes_h;    // ... and as traversed: binary16 planes, 32 B (tree_build_device.hip tb_half_planes_kernel)
     const DevTri*      fast_tris;
     uint32_t n_fast_nodes;
     int32_t  fast_max_stack;

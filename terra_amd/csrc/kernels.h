@@ -47,5 +47,5 @@ hipError_t terra_unit_distribution_2d ( const float* f, uint32_t nx, uint32_t ny
 // the fast tree built on the GPU (tree_build_device.hip): device pointers; out_nodes holds up to n - 1 nodes, out_tris n triangles
 // extra_margin: added to the +-1e-4 triangle boxes on every side (0 inside the coordinate range; the rounding bound of the reachability mode outside it)
 hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, float extra_margin, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream );
-// DevNode (min, max) -> DevFastNode (binary16 planes x scale, rounded outward, both ray signs), in place: the form the MODE-2 / 3 kernels traverse (tree_build_device.hip)
-hipError_t terra_fast_nodes_half_planes ( DevNode* nodes, uint32_t n, float scale, hipStream_t stream );
+// DevNode (min, max) -> DevFastNode (binary16 planes x scale, rounded outward): the form the MODE-2 / 3 kernels traverse (tree_build_device.hip)
+hipError_t terra_fast_nodes_half_planes ( const DevNode* nodes, uint32_t n, float scale, DevFastNode* out_nodes, hipStream_t stream );

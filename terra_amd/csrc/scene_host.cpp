@@ -626,6 +626,42 @@ static const float2* sincos_table_of ( int device ) {
     return t;
 }
 
+// Can this scene, as it stands, be rendered by this library? The reference runs ANY host callback (TerraBSDF::sample / pdf / eval, TerraAttribute::eval:
+// src/Terra.c:1071-1075, 1804-1810); the device runs the presets of TerraPresets.h and texture lookups only, and there is no CPU path here. A client that
+// supports custom callbacks asks before it commits and keeps such scenes on the reference renderer. (upload_scene applies the same rules and fails the commit.)
+static int scene_support ( const Scene* s, std::string& why ) {
+    char b[256];
+    if ( s->objects_pop > 256 ) { snprintf ( b, sizeof b, "%zu objects: the primitive reference holds 8 bits of object index (include/Terra.h:195-198)", s->objects_pop ); why = b; return kTerraAmdErrUnsupported; }
+    auto attr_ok = [&] ( const TerraAttribute & at, size_t j, const char* what ) {
+        if ( at.state == nullptr ) return true;
+        if ( at.eval != terra_texture_sample ) { snprintf ( b, sizeof b, "object %zu %s: an attribute callback other than terra_texture_sample (host code cannot run on the device)", j, what ); why = b; return false; }
+        const TerraTexture* t = ( const TerraTexture* ) at.state;
+        if ( !t->pixels || !t->width || !t->height || ( t->depth != 1 && t->depth != 4 ) || t->components == 0 ) { snprintf ( b, sizeof b, "object %zu %s: invalid texture", j, what ); why = b; return false; }
+        return true;
+    };
+    for ( size_t j = 0; j < s->objects_pop; ++j ) {
+        const TerraMaterial& m = s->objects[j].material;
+        if ( ! ( is_diffuse ( m.bsdf ) || is_phong ( m.bsdf ) || is_ggx ( m.bsdf ) || is_glass ( m.bsdf ) ) ) {
+            snprintf ( b, sizeof b, "object %zu: its BSDF's sample / pdf / eval are not a terra_bsdf_*_init preset of this library (host callbacks cannot run on the device)", j ); why = b; return kTerraAmdErrUnsupported;
+        }
+        if ( m.attributes_count > TERRA_MATERIAL_MAX_ATTRIBUTES ) { snprintf ( b, sizeof b, "object %zu: attributes_count %zu > %d", j, m.attributes_count, TERRA_MATERIAL_MAX_ATTRIBUTES ); why = b; return kTerraAmdErrBadArgument; }
+        if ( !attr_ok ( m.emissive, j, "emissive" ) ) return kTerraAmdErrUnsupported;
+        for ( size_t a = 0; a < m.attributes_count; ++a ) { char w[32]; snprintf ( w, sizeof w, "attribute %zu", a ); if ( !attr_ok ( m.attributes[a], j, w ) ) return kTerraAmdErrUnsupported; }
+    }
+    if ( s->env_lighting ) {
+        const TerraAttribute& env = s->new_opts.environment_map;
+        if ( env.state != nullptr && env.eval != terra_texture_sample_latlong ) { why = "environment: with environment lighting on, the attribute must be a constant or terra_attribute_init_cubemap"; return kTerraAmdErrUnsupported; }
+    }
+    if ( terra_amd_device_count() <= 0 ) { why = "no HIP device visible"; return kTerraAmdErrNoDevice; }
+    return 0;
+}
+extern "C" int terra_amd_scene_supported ( HTerraScene h, char* why, size_t capacity ) {
+    std::string w;
+    const int st = scene_support ( S ( h ), w );
+    if ( why && capacity ) snprintf ( why, capacity, "%s", w.c_str() );
+    return st;          // (a query: nothing is recorded in the error channels)
+}
+
 // validates that every material can run on the device and uploads the flattened scene
 static int upload_scene ( Scene* s ) {
     const size_t nobj = s->objects_pop;
@@ -868,7 +904,7 @@ static int upload_scene ( Scene* s ) {
     size_t o_mats = align ( o_props + props.size() * sizeof ( DevProps ) ), o_lights = align ( o_mats + mats.size() * sizeof ( DevMaterial ) );
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
     const size_t fn_cap = s->fast_on_device ? ntri : fnodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();      // a device build writes at most n - 1 nodes, n triangles
-    size_t o_ft = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );
+    size_t o_fh = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_ft = align ( o_fh + fn_cap * sizeof ( DevFastNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );      // (o_fh: the nodes as traversed, DevFastNode)
     const size_t n_replay = s->reach ? ( nodes.size() ? nodes.size() : 1 ) : 0, n_reach_tri = s->reach ? ntri : 0;
     const size_t o_rp = o_td, o_lp = align ( o_rp + n_replay * sizeof ( DevReplay ) ), o_lm = align ( o_lp + n_reach_tri * 4 ); o_td = align ( o_lm + n_reach_tri * 4 );
     std::vector<DevTexture> tdesc ( textures.size() );
@@ -946,13 +982,13 @@ static int upload_scene ( Scene* s ) {
         }
     }
     float fast_scale = 1.f;
-    if ( have_fast && s->fast_nodes ) {       // boxes as binary16 planes for both ray signs (DevFastNode): what the kernels traverse; everything above checked the (min, max) form
+    if ( have_fast && s->fast_nodes ) {       // boxes as binary16 planes (DevFastNode): what the kernels traverse; everything above checked the (min, max) form
         // every plane times a power of two that brings the largest of them (|coordinate| + box margin) below 2^14: binary16 reaches 65,504, and a power of two changes
         // no bit of plane or t value -- the kernel divides the ray's inverse direction by the same factor (DevScene::fast_inv_scale)
         const float reach = s->coord_max + 1e-4f + fast_extra;
         if ( std::isfinite ( reach ) ) while ( reach * fast_scale >= 16384.f && fast_scale > 0x1p-100f ) fast_scale *= 0.5f;
-        if ( s->fast_nodes >= ( 1u << 26 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address nodes by a 32-bit byte offset (at most 2^26 nodes)", s->fast_nodes );
-        hipError_t e = terra_fast_nodes_half_planes ( ( DevNode* ) ( base + o_fn ), s->fast_nodes, fast_scale, nullptr );
+        if ( s->fast_nodes >= ( 1u << 27 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address nodes by a 32-bit byte offset (at most 2^27 nodes)", s->fast_nodes );
+        hipError_t e = terra_fast_nodes_half_planes ( ( const DevNode* ) ( base + o_fn ), s->fast_nodes, fast_scale, ( DevFastNode* ) ( base + o_fh ), nullptr );
         if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "fast tree conversion: %s", hipGetErrorString ( e ) );
     }
     for ( size_t k = 0; k < textures.size(); ++k ) {
@@ -968,7 +1004,7 @@ static int upload_scene ( Scene* s ) {
     s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
     s->dev.n_nodes = ( uint32_t ) nodes.size(); s->dev.n_tris = ( uint32_t ) ntri; s->dev.n_objects = ( uint32_t ) nobj; s->dev.n_lights = ( uint32_t ) s->lights.size();
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
-    s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
+    s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_nodes_h = have_fast ? ( const DevFastNode* ) ( base + o_fh ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack; s->dev.fast_inv_scale = 1.f / fast_scale;
     s->dev.reach = ( s->reach && have_fast && !reach_tabs.leaf_parent.empty() ) ? 1u : 0u;
     s->dev.ref_replay = s->dev.reach ? ( const DevReplay* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
@@ -1027,7 +1063,7 @@ static int replicate_scene ( Scene* s ) {
         q.dev = s->dev;
         q.dev.nodes = ( const DevNode* ) move ( s->dev.nodes ); q.dev.tris = ( const DevTri* ) move ( s->dev.tris ); q.dev.props = ( const DevProps* ) move ( s->dev.props );
         q.dev.mats = ( const DevMaterial* ) move ( s->dev.mats ); q.dev.lights = ( const DevLight* ) move ( s->dev.lights ); q.dev.tri_area = ( const float* ) move ( s->dev.tri_area );
-        q.dev.textures = ( const DevTexture* ) move ( s->dev.textures ); q.dev.fast_nodes = ( const DevNode* ) move ( s->dev.fast_nodes ); q.dev.fast_tris = ( const DevTri* ) move ( s->dev.fast_tris );
+        q.dev.textures = ( const DevTexture* ) move ( s->dev.textures ); q.dev.fast_nodes = ( const DevNode* ) move ( s->dev.fast_nodes ); q.dev.fast_nodes_h = ( const DevFastNode* ) move ( s->dev.fast_nodes_h ); q.dev.fast_tris = ( const DevTri* ) move ( s->dev.fast_tris );
         q.dev.ref_replay = ( const DevReplay* ) move ( s->dev.ref_replay ); q.dev.fast_leaf_parent = ( const uint32_t* ) move ( s->dev.fast_leaf_parent ); q.dev.fast_leaf_mask = ( const uint32_t* ) move ( s->dev.fast_leaf_mask );
         if ( !s->tdesc_host.empty() ) {
             std::vector<DevTexture> td = s->tdesc_host;

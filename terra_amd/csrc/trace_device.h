@@ -487,38 +487,40 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 // (DevTri::pad of the fast soup). The triangle test itself is the same arithmetic.
 // Child word of a fast node: bit 31 leaf; leaf = (count-1) << 27 | first triangle.
 //
-// Node format in HBM (DevFastNode, 64 B = half a cache line; written in place over the builder's (min, max) node by
-// tree_build_device.hip tb_half_planes_kernel): the twelve planes of the two child boxes as binary16, rounded OUTWARD, stored
-// axis major and for BOTH ray signs --
-//     [x+] min0 max0 min1 max1   [x-] max0 min0 max1 min1   [y+] ..  [y-] ..  [z+] ..  [z-] ..   child0 child1  (8 B spare)
-// A ray reads, per axis, the 8-byte quad that matches the sign of its direction: the four halves are then (near, far) of child 0
-// and of child 1, no per-axis min / max and no select; each plane goes straight into t = fma ( plane, inv, -(o * inv) ) as the
-// binary16 operand of v_fma_mix_f32, so a box costs six fused multiply-adds, a v_max3, a v_min3 and the comparisons. Unlike the
-// reference tree's test this one only has to be CONSERVATIVE (never reject a box that holds a triangle the ray hits; DESIGN.md
-// "Traversal policy"): rounding the planes outward only widens the box, and t carries two roundings (o * inv, the fma) where the
-// commit-time error budget (scene_host.cpp "numeric containment check") allows four. Planes are stored times DevScene::fast_scale
-// (a power of two: exact) so that every scene fits binary16's range; the ray's inverse direction is divided by it (exact too).
+// Node format in HBM (DevFastNode, 32 B; written from the builder's (min, max) node by tree_build_device.hip tb_half_planes_kernel): the twelve planes of the two
+// child boxes as binary16, rounded OUTWARD, one 32-bit word (min | max << 16) per child and axis, then the two child words: TWO 16-byte loads fetch a node.
+// The render kernels of scenes read from global memory are bound by the texture addresser (profiles/r04_*: TA busy 99 % of the kernel's cycles, ~21 of its cycles per
+// wave-level load instruction whatever the instruction's width), so what counts is the NUMBER of load instructions per ray, not their bytes: the 64-byte (min, max)
+// node of rounds 2-3 took four. Per axis the ray swaps the halves of a word when it travels in the negative direction (one v_perm_b32 with a per-ray selector), so
+// that the low half is the near plane and the high half the far one; each plane then goes straight into t = fma ( plane, inv, -(o * inv) ) as the binary16 operand
+// of v_fma_mix_f32: a box costs three swaps, six fused multiply-adds, a v_max3, a v_min3 and the comparisons. Unlike the reference tree's test this one only has to
+// be CONSERVATIVE (never reject a box that holds a triangle the ray hits; DESIGN.md "Traversal policy"): rounding the planes outward only widens the box, and t
+// carries two roundings (o * inv, the fma) where the commit-time error budget (scene_host.cpp "numeric containment check") allows four. Planes are stored times
+// DevScene::fast_scale (a power of two: exact) so that every scene fits binary16's range; the ray's inverse direction is divided by it (exact too).
 // An empty child slot is an inverted box (min = +max_half, max = -max_half): never entered, so no lane ever holds it.
 // -----------------------------------------------------------------------------
 typedef _Float16 terra_half2 __attribute__ (( ext_vector_type ( 2 ) ));
 TD terra_half2 as_half2 ( uint32_t u ) { return __builtin_bit_cast ( terra_half2, u ); }
 // what a ray needs of itself for the fast tree's box test: the inverse direction -- clamped (a ray parallel to an axis has an infinite inverse direction there, and inf - inf
 // would drop that axis from the test: correct but ruinous, such a ray then visits every box along its line; clamped to +-2^100 the axis keeps its meaning: (plane - o) * 2^100
-// has the sign of "outside the slab") and divided by the planes' scale --, origin x clamped inverse direction, and the byte offset of the quad each axis reads
-struct FastRay { V3 inv, oi; uint32_t sx, sy, sz; };
+// has the sign of "outside the slab") and divided by the planes' scale --, origin x clamped inverse direction, and per axis the byte selector that puts the near plane in the low half
+struct FastRay { V3 inv, oi; uint32_t px, py, pz; };
+#define TERRA_PERM_KEEP 0x03020100u
+#define TERRA_PERM_SWAP 0x01000302u
 TD FastRay fast_ray ( const Ray& ray, float inv_scale ) {
     FastRay f;
     const float cx = __builtin_fminf ( __builtin_fmaxf ( ray.inv.x, -0x1p100f ), 0x1p100f ), cy = __builtin_fminf ( __builtin_fmaxf ( ray.inv.y, -0x1p100f ), 0x1p100f ), cz = __builtin_fminf ( __builtin_fmaxf ( ray.inv.z, -0x1p100f ), 0x1p100f );
     f.oi = v3 ( ray.o.x * cx, ray.o.y * cy, ray.o.z * cz );
     f.inv = v3 ( cx * inv_scale, cy * inv_scale, cz * inv_scale );
-    f.sx = cx < 0.f ? 8u : 0u; f.sy = cy < 0.f ? 24u : 16u; f.sz = cz < 0.f ? 40u : 32u;
+    f.px = cx < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP; f.py = cy < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP; f.pz = cz < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP;
     return f;
 }
-// entry distance of one child box from its (near, far) planes per axis; hit = the ray's interval inside the box is not empty
-TD bool slab_half ( _Float16 nx, _Float16 fx, _Float16 ny, _Float16 fy, _Float16 nz, _Float16 fz, const FastRay& f, float& t_enter ) {
-    const float tnx = __builtin_fmaf ( ( float ) nx, f.inv.x, -f.oi.x ), tfx = __builtin_fmaf ( ( float ) fx, f.inv.x, -f.oi.x );
-    const float tny = __builtin_fmaf ( ( float ) ny, f.inv.y, -f.oi.y ), tfy = __builtin_fmaf ( ( float ) fy, f.inv.y, -f.oi.y );
-    const float tnz = __builtin_fmaf ( ( float ) nz, f.inv.z, -f.oi.z ), tfz = __builtin_fmaf ( ( float ) fz, f.inv.z, -f.oi.z );
+// entry distance of one child box from its three plane words (min | max << 16 per axis); hit = the ray's interval inside the box is not empty
+TD bool slab_half ( uint32_t wx, uint32_t wy, uint32_t wz, const FastRay& f, float& t_enter ) {
+    const terra_half2 x = as_half2 ( __builtin_amdgcn_perm ( wx, wx, f.px ) ), y = as_half2 ( __builtin_amdgcn_perm ( wy, wy, f.py ) ), z = as_half2 ( __builtin_amdgcn_perm ( wz, wz, f.pz ) );      // (near, far)
+    const float tnx = __builtin_fmaf ( ( float ) x.x, f.inv.x, -f.oi.x ), tfx = __builtin_fmaf ( ( float ) x.y, f.inv.x, -f.oi.x );
+    const float tny = __builtin_fmaf ( ( float ) y.x, f.inv.y, -f.oi.y ), tfy = __builtin_fmaf ( ( float ) y.y, f.inv.y, -f.oi.y );
+    const float tnz = __builtin_fmaf ( ( float ) z.x, f.inv.z, -f.oi.z ), tfz = __builtin_fmaf ( ( float ) z.y, f.inv.z, -f.oi.z );
     t_enter = __builtin_fmaxf ( __builtin_fmaxf ( __builtin_fmaxf ( tnx, tny ), tnz ), 0.f );
     return __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz ) > t_enter;
 }
@@ -571,10 +573,8 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 template <int COUNT>
 TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c, bool checked = false ) {
     const FastRay f = fast_ray ( ray, T.sc.fast_inv_scale );
-    const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes );
-    const char* tris = reinterpret_cast<const char*> ( T.sc.fast_tris );
-    // the vertex components the triangle test reads, as byte offsets inside a 48-byte triangle: the ray's (kx, ky, kz) axes select the ADDRESS, not the loaded value
-    const uint32_t kx4 = ( uint32_t ) st.ix << 2, ky4 = ( uint32_t ) st.iy << 2, kz4 = ( uint32_t ) st.iz << 2;
+    const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes_h );
+    const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
     // `cur`: the node a lane descends into next stays in a register (the near child when both are hit); only the far child
     // goes through the stack, so a descent step does not wait for an LDS write + read of its own
     uint32_t cur = DEV_CHILD_EMPTY;
@@ -592,17 +592,16 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
                 cur = DEV_CHILD_EMPTY;
                 if ( w & DEV_CHILD_LEAF ) leaf = w;                  // (a far child that was a leaf comes off the stack)
                 else {
-                    const uint32_t off = w << 6;
-                    const uint2 qx = *reinterpret_cast<const uint2*> ( nodes + ( off + f.sx ) ), qy = *reinterpret_cast<const uint2*> ( nodes + ( off + f.sy ) ), qz = *reinterpret_cast<const uint2*> ( nodes + ( off + f.sz ) );
-                    const uint2 ch = *reinterpret_cast<const uint2*> ( nodes + ( off + 48u ) );
+                    const uint32_t off = w << 5;
+                    const uint4 q0 = *reinterpret_cast<const uint4*> ( nodes + off ), q1 = *reinterpret_cast<const uint4*> ( nodes + ( off + 16u ) );      // {x0 y0 z0 x1} {y1 z1 child0 child1}
+                    const uint2 ch = make_uint2 ( q1.z, q1.w );
                     if ( COUNT ) ++c.nodes;
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
-                    const terra_half2 x0 = as_half2 ( qx.x ), x1 = as_half2 ( qx.y ), y0 = as_half2 ( qy.x ), y1 = as_half2 ( qy.y ), z0 = as_half2 ( qz.x ), z1 = as_half2 ( qz.y );
                     float te0, te1;
-                    const bool hit0 = slab_half ( x0.x, x0.y, y0.x, y0.y, z0.x, z0.y, f, te0 ) && te0 <= best.depth;
-                    const bool hit1 = slab_half ( x1.x, x1.y, y1.x, y1.y, z1.x, z1.y, f, te1 ) && te1 <= best.depth;
+                    const bool hit0 = slab_half ( q0.x, q0.y, q0.z, f, te0 ) && te0 <= best.depth;
+                    const bool hit1 = slab_half ( q0.w, q1.x, q1.y, f, te1 ) && te1 <= best.depth;
                     const bool one_near = hit1 && ! ( hit0 && te0 <= te1 );          // child 1 is the one to enter first
                     const uint32_t near = one_near ? ch.y : ch.x, far = one_near ? ch.x : ch.y;
                     if ( hit0 && hit1 ) {
@@ -618,12 +617,12 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
             const uint32_t ti = leaf & 0x07ffffffu;
             leaf = ( leaf & 0x78000000u ) ? leaf + 1u - 0x08000000u : 0u;        // next triangle of the leaf, one fewer to go; 0 = nothing in hand
-            const uint32_t t48 = ti * 48u;
-            const char* ta = tris + ( t48 + kx4 ); const char* tb = tris + ( t48 + ky4 ); const char* tc = tris + ( t48 + kz4 );
-            const float pa[3] = { *reinterpret_cast<const float*> ( ta ), *reinterpret_cast<const float*> ( tb ), *reinterpret_cast<const float*> ( tc ) };
-            const float pb[3] = { *reinterpret_cast<const float*> ( ta + 16 ), *reinterpret_cast<const float*> ( tb + 16 ), *reinterpret_cast<const float*> ( tc + 16 ) };
-            const float pc[3] = { *reinterpret_cast<const float*> ( ta + 32 ), *reinterpret_cast<const float*> ( tb + 32 ), *reinterpret_cast<const float*> ( tc + 32 ) };
-            const uint32_t rank = *reinterpret_cast<const uint32_t*> ( tris + ( t48 + 44u ) );
+            const float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];          // three loads: every wave-level load instruction costs the texture addresser the same ~21 cycles
+            const V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+            const float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
+            const float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
+            const float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
+            const uint32_t rank = __float_as_uint ( cc.w );
             if ( COUNT ) ++c.tri_tests;
             float depth;
             if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {

@@ -217,11 +217,10 @@ hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* ra
 }
 
 // -----------------------------------------------------------------------------
-// Traversal form of a fast-tree node (dev_types.h DevFastNode; the traversal is trace_device.h traverse_fast_resume): each child
+// Traversal form of a fast-tree node (dev_types.h DevFastNode, 32 B; the traversal is trace_device.h traverse_fast_resume): each child
 // box (min, max) becomes six binary16 planes, times `scale` (a power of two chosen by the host so that every plane fits binary16's
-// range), rounded OUTWARD -- min down, max up -- and stored for both ray signs. The new box CONTAINS the old one, which is all the
-// fast tree's traversal needs (DESIGN.md "Traversal policy"); the commit-time containment check runs on the (min, max) boxes before
-// this. Written in place: a thread reads its node's 64 bytes, then writes 64 bytes.
+// range), rounded OUTWARD -- min down, max up. The new box CONTAINS the old one, which is all the fast tree's traversal needs
+// (DESIGN.md "Traversal policy"); the commit-time containment check runs on the (min, max) boxes before this.
 // -----------------------------------------------------------------------------
 // x -> the largest binary16 <= x (DOWN) or the smallest >= x (up), as bits. HIP's __float2half_rd / _ru are not relied upon (their rounding is not
 // pinned across ROCm releases): round to nearest, then step one binary16 towards the wanted side if that went the wrong way. +-inf results are fine (wider).
@@ -237,30 +236,28 @@ __device__ __forceinline__ uint16_t half_outward ( double x ) {      // (a doubl
     }
     return u;
 }
-__global__ __launch_bounds__ ( 256 ) void tb_half_planes_kernel ( DevNode* nodes, uint32_t n, float scale ) {
+__global__ __launch_bounds__ ( 256 ) void tb_half_planes_kernel ( const DevNode* nodes, uint32_t n, float scale, DevFastNode* out_nodes ) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if ( i >= n ) return;
     const DevNode nd = nodes[i];
     DevFastNode out;
     #pragma unroll
-    for ( int a = 0; a < 3; ++a ) {
-        uint16_t lo[2], hi[2];
+    for ( int k = 0; k < 2; ++k ) {
         #pragma unroll
-        for ( int k = 0; k < 2; ++k ) {
+        for ( int a = 0; a < 3; ++a ) {
             const float mn = ( k ? nd.min1 : nd.min0 ) [a], mx = ( k ? nd.max1 : nd.max0 ) [a];
             const bool empty = nd.child[k] == DEV_CHILD_EMPTY || !( mn <= mx );
-            lo[k] = empty ? ( uint16_t ) 0x7bffu : half_outward<true> ( ( double ) mn * ( double ) scale );      // an empty slot: min = +65504, max = -65504 -- no ray enters it
-            hi[k] = empty ? ( uint16_t ) 0xfbffu : half_outward<false> ( ( double ) mx * ( double ) scale );
+            const uint32_t lo = empty ? 0x7bffu : half_outward<true> ( ( double ) mn * ( double ) scale );      // an empty slot: min = +65504, max = -65504 -- no ray enters it
+            const uint32_t hi = empty ? 0xfbffu : half_outward<false> ( ( double ) mx * ( double ) scale );
+            out.p[k][a] = lo | ( hi << 16 );
         }
-        out.q[2 * a][0] = lo[0]; out.q[2 * a][1] = hi[0]; out.q[2 * a][2] = lo[1]; out.q[2 * a][3] = hi[1];
-        out.q[2 * a + 1][0] = hi[0]; out.q[2 * a + 1][1] = lo[0]; out.q[2 * a + 1][2] = hi[1]; out.q[2 * a + 1][3] = lo[1];
+        out.child[k] = nd.child[k];
     }
-    out.child[0] = nd.child[0]; out.child[1] = nd.child[1]; out.spare[0] = 0; out.spare[1] = 0;
-    *reinterpret_cast<DevFastNode*> ( &nodes[i] ) = out;
+    out_nodes[i] = out;
 }
-hipError_t terra_fast_nodes_half_planes ( DevNode* nodes, uint32_t n, float scale, hipStream_t stream ) {
+hipError_t terra_fast_nodes_half_planes ( const DevNode* nodes, uint32_t n, float scale, DevFastNode* out_nodes, hipStream_t stream ) {
     if ( n == 0 ) return hipSuccess;
-    hipLaunchKernelGGL ( tb_half_planes_kernel, dim3 ( ( n + 255 ) / 256 ), dim3 ( 256 ), 0, stream, nodes, n, scale );
+    hipLaunchKernelGGL ( tb_half_planes_kernel, dim3 ( ( n + 255 ) / 256 ), dim3 ( 256 ), 0, stream, nodes, n, scale, out_nodes );
     hipError_t e = hipGetLastError();
     return e != hipSuccess ? e : hipStreamSynchronize ( stream );
 }

@@ -18,6 +18,7 @@ import numpy as np
 from . import api
 
 FRAME_SEED = 0x5EED0001
+LAST_COMMIT_MS = 0.0
 
 
 @dataclass
@@ -487,7 +488,11 @@ def build_scene(lib: api.TerraLib, d: SceneDesc, tree_mode=None, tree_builder=No
         obj = lib.scene_add_object(scene, len(od.triangles)).contents
         fill_object(lib, obj, od)
     apply_options(lib, scene, d)
+    import time
+    t = time.perf_counter()
     lib.scene_commit(scene)
+    global LAST_COMMIT_MS
+    LAST_COMMIT_MS = (time.perf_counter() - t) * 1e3       # wall time of terra_scene_commit alone: host tree build(s), flattening, upload (bench.py reports it)
     return scene
 
 
