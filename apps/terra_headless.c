@@ -30,7 +30,7 @@
  *   terra_headless scene.obj out.png [--width W] [--height H] [--spp N] [--bounces N]
  *       [--integrator simple|direct|mis|normals|depth] [--tonemap none|linear|reinhard|filmic|uncharted2]
  *       [--camera px py pz dx dy dz] [--fov deg] [--exposure e] [--gamma g] [--jitter j]
- *       [--no-flip-z] [--normals apollo|file] [--dump-scene file] [--no-render] [--fast-tree | --replica-tree] [--sample-split n] [--seed n] [--tile n]
+ *       [--no-flip-z] [--normals apollo|file] [--dump-scene file] [--no-render] [--fast-tree | --replica-tree] [--sample-split n] [--seed n] [--tile n] [--gpus n]
  */
 #include <ctype.h>
 #include <math.h>
@@ -44,6 +44,9 @@ const char* terra_amd_last_error ( void ) __attribute__ ( ( weak ) );
 int         terra_amd_set_tree_mode ( HTerraScene, int ) __attribute__ ( ( weak ) );
 int         terra_amd_set_sample_split ( HTerraScene, int ) __attribute__ ( ( weak ) );
 void        terra_amd_set_frame_seed ( HTerraScene, uint64_t ) __attribute__ ( ( weak ) );
+int         terra_amd_set_devices ( const int*, int ) __attribute__ ( ( weak ) );
+int         terra_amd_device_count ( void ) __attribute__ ( ( weak ) );
+int         terra_amd_render_multi ( const TerraCamera*, HTerraScene, const TerraFramebuffer*, size_t, size_t, size_t, size_t, size_t ) __attribute__ ( ( weak ) );
 
 /* ---- growable arrays ------------------------------------------------------------------------ */
 #define VEC(T) struct { T* d; size_t n, cap; }
@@ -433,6 +436,8 @@ static const char* kHelp =
     "  --width W --height H --spp N --bounces N --integrator simple|direct|mis|normals|depth --tonemap none|linear|reinhard|filmic|uncharted2\n"
     "  --camera px py pz dx dy dz --fov deg --exposure e --gamma g --jitter j --no-flip-z --normals apollo|file\n"
     "  --dump-scene file --no-render --fast-tree | --replica-tree --sample-split n --seed n --tile n\n"
+    "  --gpus N (libterra_amd.so only): the scene is replicated on the first N GPUs and the frame's 64-pixel tiles are dealt to them from this one process, one RCCL\n"
+    "           gather at the end (terra_amd_set_devices / terra_amd_render_multi); N = 1 runs the same calls on one GPU. Without it: terra_render() on one GPU.\n"
     "OBJ/MTL import (--normals apollo, the default): the policy of the reference client's importer (satellite/include/Apollo.h under the\n"
     "options of satellite/src/Scene.cpp:83-93) RESTATED in this tool and pinned by hand-derived fixtures -- restated, not executed: Apollo.h\n"
     "does not compile with this image's toolchains. Everything after the TerraObject fill (commit, render, export) is the pinned path.\n";
@@ -441,7 +446,7 @@ int main ( int argc, char** argv ) {
     for ( int i = 1; i < argc; ++i ) if ( !strcmp ( argv[i], "--help" ) || !strcmp ( argv[i], "-h" ) ) { fputs ( kHelp, stdout ); return 0; }
     if ( argc < 3 ) { fprintf ( stderr, "usage: terra_headless scene.obj out.{png,ppm,pfm,hdr} [options]\n" ); return 64; }
     size_t W = 800, H = 600, spp = 8, bounces = 4, tile = 0;     /* defaults of satellite/include/Config.hpp:19-113 */
-    int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = -1, have_seed = 0, split = -1, apollo = 1;
+    int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = -1, have_seed = 0, split = -1, apollo = 1, gpus = 0;
     const char* dump_path = NULL; int no_render = 0;
     float fov = 45.f, exposure = 1.f, gamma = 2.2f, jitter = 0.f;
     unsigned long long seed = 0;
@@ -467,6 +472,7 @@ int main ( int argc, char** argv ) {
         else if ( !strcmp ( a, "--dump-scene" ) ) dump_path = NEXT();
         else if ( !strcmp ( a, "--no-render" ) ) no_render = 1;
         else if ( !strcmp ( a, "--sample-split" ) ) split = atoi ( NEXT() );
+        else if ( !strcmp ( a, "--gpus" ) ) gpus = atoi ( NEXT() );
         else if ( !strcmp ( a, "--integrator" ) ) { static const char* const n[] = { "simple", "direct", "mis", "mono", "depth", "normals", "misweights" }; integrator = pick ( NEXT(), n, 7, integrator ); }
         else if ( !strcmp ( a, "--tonemap" ) ) { static const char* const n[] = { "none", "linear", "reinhard", "filmic", "uncharted2" }; tonemap = pick ( NEXT(), n, 5, tonemap ); }
         else if ( !strcmp ( a, "--camera" ) && i + 6 < argc ) {
@@ -491,10 +497,18 @@ int main ( int argc, char** argv ) {
     if ( fast >= 0 && terra_amd_set_tree_mode ) terra_amd_set_tree_mode ( scene, fast );
     if ( split >= 0 && terra_amd_set_sample_split ) terra_amd_set_sample_split ( scene, split );
     if ( have_seed && terra_amd_set_frame_seed ) terra_amd_set_frame_seed ( scene, seed );
+    if ( gpus > 0 ) {          /* several GPUs from this one process: the first `gpus` devices, the first of them primary */
+        int devs[64];
+        if ( !terra_amd_set_devices || !terra_amd_render_multi ) { fprintf ( stderr, "terra_headless: --gpus needs libterra_amd.so\n" ); return 64; }
+        if ( gpus > 64 || ( terra_amd_device_count && gpus > terra_amd_device_count() ) ) { fprintf ( stderr, "terra_headless: --gpus %d but %d visible\n", gpus, terra_amd_device_count ? terra_amd_device_count() : 0 ); return 69; }
+        for ( int k = 0; k < gpus; ++k ) devs[k] = k;
+        if ( terra_amd_set_devices ( devs, gpus ) != 0 ) { fprintf ( stderr, "terra_headless: %s\n", terra_amd_last_error ? terra_amd_last_error() : "terra_amd_set_devices failed" ); return 69; }
+    }
     terra_scene_commit ( scene );
     TerraFramebuffer fb;
     if ( !terra_framebuffer_create ( &fb, W, H ) ) { fprintf ( stderr, "terra_headless: bad framebuffer size\n" ); return 65; }
-    if ( tile == 0 ) terra_render ( &cam, scene, &fb, 0, 0, W, H );
+    if ( gpus > 0 ) ( void ) terra_amd_render_multi ( &cam, scene, &fb, 0, 0, W, H, tile );      /* (tile = the shard's tile size here; 0 = 64) */
+    else if ( tile == 0 ) terra_render ( &cam, scene, &fb, 0, 0, W, H );
     else for ( size_t y = 0; y < H; y += tile ) for ( size_t x = 0; x < W; x += tile ) terra_render ( &cam, scene, &fb, x, y, W - x < tile ? W - x : tile, H - y < tile ? H - y : tile );
     if ( terra_amd_last_error && *terra_amd_last_error() ) { fprintf ( stderr, "terra_headless: %s\n", terra_amd_last_error() ); return 70; }
     if ( !write_image ( argv[2], &fb ) ) { fprintf ( stderr, "terra_headless: cannot write %s\n", argv[2] ); return 73; }

@@ -149,6 +149,9 @@ int  terra_amd_debug_shrink_reference_boxes ( HTerraScene scene, float amount );
    lets a test drive the launch path of trees deeper than 64 KB of LDS per block -- which the reference's own builder only produces on inputs of pathological size -- with an
    ordinary scene. The image does not change. A plan beyond what a block can hold fails the call with a message, as a real tree of that depth would. */
 int  terra_amd_debug_pad_stack ( HTerraScene scene, int entries );
+/* TEST HOOK, off by default (0): fast-tree launches of this scene keep only `entries` entries of a lane's traversal stack in LDS (default: 16) and the rest in HBM, so that
+   an ordinary scene exercises the HBM part, which rays of real scenes almost never reach. The image does not change. */
+int  terra_amd_debug_fast_stack_lds ( HTerraScene scene, int entries );
 
 /* Sample split: how many lanes share one pixel. With split = S (a power of two up to 64; default 1) a render call of
    spp samples per pixel runs as S chunks of spp/S samples on S lanes, chunk j drawing from the random
@@ -323,6 +326,9 @@ int terra_amd_unit_camera ( const TerraCamera* camera, size_t fb_width, size_t f
 int terra_amd_unit_tonemap ( int op, float gamma, int n, float* colors3 );
 /* device math: fn 0 sinf, 1 cosf, 2 powf(x,y), 3 acosf, 4 atan2f(x,y) */
 int terra_amd_unit_math ( int fn, int n, const float* x, const float* y, float* out );
+/* The plane values of the fast tree's nodes: x[i] rounded to binary16 towards -inf (up = 0) or +inf (up != 0), as bits -- so that a box of such planes
+   contains the box it was made from (host arithmetic; no device needed) */
+int terra_amd_unit_half_outward ( const double* x, int n, int up, uint16_t* out );
 /* SURVEY.md 8f N4, unit level. The reference constructs these samplers and never draws from them on the render path
    (src/Terra.c:535-548) and nothing calls its distributions; they are provided and pinned as stand-alone device functions.
    terra_sampler_stratified_next_pair (src/Terra.c:714-723) for one sampler per seed: out2[nseeds][n][2]; n <= strata^2 * samples_per_stratum */

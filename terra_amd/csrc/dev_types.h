@@ -38,14 +38,15 @@ struct DevNode {
 };
 static_assert ( sizeof ( DevNode ) == 64, "DevNode must be 64 bytes" );
 
-// A fast-tree node as the kernels read it (trace_device.h "MODE 2"), 32 bytes = two 16-byte loads: per child and axis the two planes of the child's box as binary16
-// rounded outward (min down, max up), times DevScene's power-of-two scale -- p[child][axis] = min | max << 16 --, then the child words as in DevNode (inner: node
-// index; leaf: DEV_CHILD_LEAF | (count - 1) << 27 | first triangle). An empty slot is an inverted box (min = +65504, max = -65504).
+// A fast-tree node as the kernels read it (trace_device.h "MODE 2"), 64 bytes = four 16-byte loads, FOUR children: per child and axis the two planes of the child's
+// box as binary16 rounded outward (min down, max up), times DevScene's power-of-two scale -- p[child][axis] = min | max << 16 --, then the four child words (inner:
+// index of a wide node; leaf: DEV_CHILD_LEAF | (count - 1) << 27 | first triangle; DEV_CHILD_EMPTY with an inverted box -- min = +65504, max = -65504 -- for a
+// slot not in use). Made on the host from the builders' binary tree (tree_build.cpp fastbvh::widen).
 struct DevFastNode {
-    uint32_t p[2][3];
-    uint32_t child[2];
+    uint32_t p[4][3];
+    uint32_t child[4];
 };
-static_assert ( sizeof ( DevFastNode ) == 32, "DevFastNode must be 32 bytes" );
+static_assert ( sizeof ( DevFastNode ) == 64, "DevFastNode must be 64 bytes" );
 
 struct DevTri {
     float    a[3]; uint32_t object;
@@ -115,11 +116,11 @@ struct DevScene {
     // optional second accelerator over the same triangles (terra_amd_set_tree_mode, DESIGN.md "Fast tree"):
     // 3-axis binned-SAH BVH2, leaves of up to 4 triangles; fast_tris is the soup in leaf order with
     // DevTri::pad = the triangle's rank in the REFERENCE tree's leaf visit order (the tie-break key)
-    const DevNode*     fast_nodes;      // as built: (min, max) boxes, 64 B (what the containment check reads; the kernels do not)
-    const DevFastNode* fast_nodes_h;    // ... and as traversed: binary16 planes, 32 B (tree_build_device.hip tb_half_planes_kernel)
+    const DevNode*     fast_nodes;      // the device builder's output: a binary tree with (min, max) boxes (read back, checked and widened by the host; nullptr for host-built trees)
+    const DevFastNode* fast_nodes_h;    // the tree as traversed: 4-wide nodes of binary16 planes (tree_build.cpp fastbvh::widen)
     const DevTri*      fast_tris;
-    uint32_t n_fast_nodes;
-    int32_t  fast_max_stack;
+    uint32_t n_fast_nodes;              // wide nodes
+    int32_t  fast_max_stack;            // stack entries a ray can need in the wide tree
     float    fast_inv_scale;            // 1 / (the power of two DevFastNode's planes are stored times): the factor of the ray's inverse direction
     // scenes outside the coordinate range of the containment proof (DESIGN.md "Reachability"): the fast tree (boxes inflated to the rounding bound) finds the
     // candidates, and one is accepted only if the REFERENCE traversal would have reached it, i.e. if the slab tests of its ancestors in the reference tree pass.
@@ -205,6 +206,9 @@ struct DevRenderParams {
     // lds_nodes nodes (breadth-first prefix) and lds_tris triangles (+ their vertex properties)
     // staged; leaf_cap deferred-leaf entries per thread; lds_mode 0 = nothing staged, 1 = whole scene
     uint32_t stack_depth, leaf_cap, lds_nodes, lds_tris;
+    // fast-tree launches: entries of a lane's traversal stack beyond the stack_depth kept in LDS live in HBM -- stack_spill[(resident lane) * spill_cap + (entry - stack_depth)]
+    // (the launch's scratch; nullptr when the whole stack fits in LDS). Rarely touched: the LDS part covers the depth a ray actually reaches, the bound is the tree's worst case.
+    uint32_t* stack_spill; uint32_t spill_cap;
     int32_t  lds_mode;
     int32_t  count_level;           // work counters: 0 none (the default), 2 all six per lane (terra_amd_set_work_counters, or a per-pixel draw-count buffer was passed)
     uint32_t bsdf_kinds;            // mask of DevBsdfKind present in the scene (bit k = kind k)

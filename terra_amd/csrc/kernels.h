@@ -18,6 +18,7 @@ bool       terra_scene_fits_lds ( uint32_t n_nodes, uint32_t n_tris, int max_sta
 void       terra_plan_lds ( DevRenderParams& p );     // fills stack_depth / lds_nodes / lds_tris / lds_mode
 size_t     terra_lds_bytes ( const DevRenderParams& p );   // dynamic LDS per block of the planned launch
 size_t     terra_lds_block_limit ( void );                // the most a block may ask for (launch_instance opts in above 64 KB)
+size_t     terra_fast_spill_bytes ( const DevRenderParams& p );   // bytes of DevRenderParams::stack_spill a fast-tree launch needs (p.job_blocks set; 0: the stack fits in LDS)
 void       terra_plan_fast_tree ( DevRenderParams& p );     // the plan of a fast-tree (MODE 2 / 3) launch: stack from the tree's depth, nothing staged
 hipError_t terra_launch_tiles ( bool pack, float* pixels, void* results, uint32_t fb_w, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
                                 uint32_t tile, uint32_t rank, uint32_t world, float* packed, hipStream_t stream );
@@ -47,5 +48,3 @@ hipError_t terra_unit_distribution_2d ( const float* f, uint32_t nx, uint32_t ny
 // the fast tree built on the GPU (tree_build_device.hip): device pointers; out_nodes holds up to n - 1 nodes, out_tris n triangles
 // extra_margin: added to the +-1e-4 triangle boxes on every side (0 inside the coordinate range; the rounding bound of the reachability mode outside it)
 hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* rank, uint32_t n, float extra_margin, DevNode* out_nodes, DevTri* out_tris, uint32_t* n_nodes_out, int* max_stack_out, hipStream_t stream );
-// DevNode (min, max) -> DevFastNode (binary16 planes x scale, rounded outward): the form the MODE-2 / 3 kernels traverse (tree_build_device.hip)
-hipError_t terra_fast_nodes_half_planes ( const DevNode* nodes, uint32_t n, float scale, DevFastNode* out_nodes, hipStream_t stream );

@@ -82,6 +82,7 @@ TD Tracer make_tracer ( const DevScene& sc, float4* lds, uint32_t stack_depth, u
     T.leaves = words + stack_depth * TERRA_COL + tid;
     T.leaf_cap = ( int ) leaf_cap;
     T.stack_cap = ( int ) stack_depth - TERRA_CHECK_SHRINK;      // TERRA_CHECK_SHRINK > 0: positive control of the bounds check
+    T.stack_lim = ( uint32_t ) ( uintptr_t ) words + stack_depth * 1024u; T.spill = nullptr; T.spill_cap = 0;      // (fast-tree launches: the kernel sets the spill area)
     T.faults = nullptr;
     T.cull = cull; T.fused = cull && fused;
     const float4* gn = reinterpret_cast<const float4*> ( sc.nodes );
@@ -425,6 +426,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     const int tid = threadIdx.x;
     Tracer T0 = make_tracer<MODE> ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0, p.fused_slab != 0 );
     T0.faults = p.counters + kCtrFaults;
+    if ( MODE >= 2 && p.stack_spill ) { T0.spill = p.stack_spill + ( size_t ) ( blockIdx.x * 256u + threadIdx.x ) * p.spill_cap; T0.spill_cap = p.spill_cap - TERRA_CHECK_SHRINK; }
     const Tracer T = T0;
 
     PixelStreams rs = trng_pixel_streams ( 0, 0, 0 );
@@ -681,11 +683,26 @@ size_t terra_lds_bytes ( const DevRenderParams& p ) {
     return ( size_t ) ( p.stack_depth + p.leaf_cap + ( p.lds_mode == 1 ? TERRA_AUX_WORDS_LDS : TERRA_AUX_WORDS ) ) * 1024 + ( size_t ) p.lds_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) p.lds_tris * ( 48 + 64 )
            + ( p.lds_mode == 1 ? scene_extra_lds_bytes ( p.scene.n_objects, p.scene.n_lights, p.scene.n_tris ) : 0 );
 }
-// fast tree (MODE 2 / 3): nothing is staged. A lane holds at most one leaf (in a register), so there is no leaf list; the stack has the tree's depth + 1 entries.
-// (Rounds 2-3 staged the first 64 nodes as plain 64-byte nodes read through a flat load: +3.7 % then; the binary16 node's three sign-selected 8-byte reads per
-// step would each need their own 64-bit address for that, more than the prefix returns -- the top levels now come from the L1 like every other hot line.)
+// fast tree (MODE 2 / 3): nothing is staged. A lane holds at most one leaf (in a register), so there is no leaf list. The stack: its first TERRA_FAST_STACK_LDS entries
+// in LDS (1 KB per entry and block), the rest -- up to the tree's worst case, which a ray almost never reaches -- in HBM, 4 bytes per entry and resident lane
+// (DevRenderParams::stack_spill, part of the launch's scratch: trace_device.h fast_push / fast_pop). Depth no longer decides whether a tree can be launched.
+// (Rounds 2-3 staged the first 64 nodes as plain 64-byte nodes read through a flat load: +3.7 % then. Flat loads go through the texture addresser like global ones,
+// and that unit is what binds these kernels: nothing is gained by it now.)
+#ifndef TERRA_FAST_STACK_LDS
+#define TERRA_FAST_STACK_LDS 16
+#endif
 void terra_plan_fast_tree ( DevRenderParams& p ) {
-    p.lds_mode = 2; p.lds_tris = 0; p.lds_nodes = 0; p.leaf_cap = 0; p.stack_depth = ( uint32_t ) ( p.scene.fast_max_stack < 1 ? 1 : p.scene.fast_max_stack );
+    const uint32_t need = ( uint32_t ) ( p.scene.fast_max_stack < 1 ? 1 : p.scene.fast_max_stack );
+    p.lds_mode = 2; p.lds_tris = 0; p.lds_nodes = 0; p.leaf_cap = 0; p.stack_depth = need < ( uint32_t ) TERRA_FAST_STACK_LDS ? need : ( uint32_t ) TERRA_FAST_STACK_LDS;
+    p.spill_cap = need - p.stack_depth; p.stack_spill = nullptr;
+}
+// resident lanes a fast-tree launch can have at most (8 blocks of 256 threads per CU): what the spill area is sized for
+size_t terra_fast_spill_bytes ( const DevRenderParams& p ) {
+    if ( p.lds_mode != 2 || p.spill_cap == 0 ) return 0;
+    int cus = 0, dev = 0; ( void ) hipGetDevice ( &dev );
+    if ( hipDeviceGetAttribute ( &cus, hipDeviceAttributeMultiprocessorCount, dev ) != hipSuccess || cus < 1 ) { ( void ) hipGetLastError(); cus = 256; }
+    const size_t blocks = ( size_t ) p.job_blocks < ( size_t ) cus * 8 ? ( size_t ) p.job_blocks : ( size_t ) cus * 8;
+    return blocks * 256 * ( size_t ) p.spill_cap * sizeof ( uint32_t );
 }
 
 // LDS plan. Small scenes (whole scene + stack + a leaf list of at least TERRA_LEAF_CAP_RESIDENT_MIN entries <= budget): stage
@@ -771,6 +788,7 @@ static hipError_t launch_instance ( const DevRenderParams& p, size_t lds, hipStr
     }
     uint32_t grid = p.job_blocks;
     if ( p.job_queue ) { const uint32_t cap = resident_blocks ( reinterpret_cast<const void*> ( fn ), lds ); if ( grid > cap ) grid = cap; }
+    if ( MODE >= 2 && p.spill_cap && ( !p.stack_spill || ( size_t ) grid * 256 * p.spill_cap * sizeof ( uint32_t ) > terra_fast_spill_bytes ( p ) ) ) return hipErrorInvalidValue;      // (the spill area is sized for 8 blocks per CU)
     hipLaunchKernelGGL ( fn, dim3 ( grid ), dim3 ( 256 ), lds, stream, p );
     return hipGetLastError();
 }

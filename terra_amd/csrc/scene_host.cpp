@@ -276,7 +276,7 @@ struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 #endif
 #define TERRA_REACH_MAX_COORD 1e6f       // beyond it (c - o) x 2^100 (the fast tree's clamped slab test) approaches the binary32 range: replica
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
-#define TERRA_FAST_STACK_AUX_KB 6                   // render_kernels.hip TERRA_AUX_WORDS: a fast-tree launch needs (depth + aux words) KB of LDS per block
+#define TERRA_FAST_STACK_MAX 2048                   // stack entries per ray beyond which the fast tree is not used (its spill space: 4 B x entries x 327,680 resident lanes)
 struct Scene {
     TerraSceneOptions opts, new_opts;
     TerraObject* objects = nullptr; size_t objects_pop = 0, objects_cap = 0;
@@ -323,6 +323,7 @@ struct Scene {
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
     int test_pad_stack = 0;                         // terra_amd_debug_pad_stack (tests only): extra stack entries every launch plans
+    int test_fast_stack_lds = 0;                    // terra_amd_debug_fast_stack_lds (tests only): entries of a fast-tree launch's stack kept in LDS (0: the default), the rest spills to HBM
     float test_shrink_reference_boxes = 0.f;       // terra_amd_debug_shrink_reference_boxes (tests only): the device copy of the reference tree's boxes is shrunk by this much
 };
 
@@ -380,6 +381,11 @@ extern "C" int terra_amd_debug_shrink_reference_boxes ( HTerraScene h, float amo
 extern "C" int terra_amd_debug_pad_stack ( HTerraScene h, int entries ) {
     if ( entries < 0 || entries > 4096 ) return fail ( kTerraAmdErrBadArgument, "stack padding must be 0 .. 4096 entries" );
     S ( h )->test_pad_stack = entries;
+    return 0;
+}
+extern "C" int terra_amd_debug_fast_stack_lds ( HTerraScene h, int entries ) {
+    if ( entries < 0 || entries > 4096 ) return fail ( kTerraAmdErrBadArgument, "LDS stack entries must be 0 (default) .. 4096" );
+    S ( h )->test_fast_stack_lds = entries;
     return 0;
 }
 extern "C" int terra_amd_traversal_info ( HTerraScene h, TerraAmdTraversalInfo* out ) {
@@ -786,6 +792,7 @@ static int upload_scene ( Scene* s ) {
     }
     // optional fast tree: same triangles, own node array and leaf-ordered soup with reference visit ranks
     std::vector<DevNode> fnodes; std::vector<DevTri> ftris; std::vector<uint32_t> rank_for_device;
+    fastbvh::Wide fwide;                // the fast tree as traversed: 4-wide nodes of binary16 planes
     ReachTables reach_tabs;
     s->fast_nodes = 0; s->fast_max_stack = 1; s->fast_on_device = false;
     // traversal policy (see Scene::tree_mode and the containment check above)
@@ -843,6 +850,10 @@ static int upload_scene ( Scene* s ) {
     }
     s->use_fast = s->tree_mode == 1 || ( auto_ok && !resident ) || s->reach;
     const float fast_extra = ( s->reach && reach_margin > 1e-4f ) ? reach_margin - 1e-4f : 0.f;      // on top of the +-1e-4 of every triangle box
+    // the fast tree's planes are stored as binary16 times a power of two that brings the largest of them (|coordinate| + box margin) below 2^14: binary16 reaches 65,504,
+    // and a power of two changes no bit of a plane or a t value -- the kernel divides the ray's inverse direction by the same factor (DevScene::fast_inv_scale)
+    float fast_scale = 1.f;
+    { const float span = s->coord_max + 1e-4f + fast_extra; if ( std::isfinite ( span ) ) while ( span * fast_scale >= 16384.f && fast_scale > 0x1p-100f ) fast_scale *= 0.5f; }
     std::vector<uint32_t> soup_of_fast;                                                             // reach: soup index of every fast triangle (host-built: known here)
     if ( s->use_fast ) {
         // rank of every soup triangle in the reference traversal's leaf visit order (all boxes hit)
@@ -882,19 +893,24 @@ static int upload_scene ( Scene* s ) {
                 built.nodes.clear(); built.order.clear();
             }
             fnodes.swap ( built.nodes );
+            if ( s->use_fast ) {
+                double t_w = now_s();
+                fwide = fastbvh::widen ( fnodes, fast_scale );
+                phase ( "  4-wide binary16 nodes", t_w );
+            }
             ftris.resize ( ntri ? ntri : 1 );
             for ( size_t k = 0; k < built.order.size(); ++k ) { ftris[k] = tris[built.order[k]]; ftris[k].pad = rank[built.order[k]]; }
             if ( s->reach && s->use_fast ) soup_of_fast = built.order;
-            s->fast_nodes = ( uint32_t ) fnodes.size(); s->fast_max_stack = built.max_stack;
+            s->fast_nodes = ( uint32_t ) fwide.nodes.size(); s->fast_max_stack = fwide.max_stack;
         }
     }
     if ( s->tree_mode == 2 && s->reach && !s->use_fast ) { s->reach = false; }
-    // the stack of a fast-tree launch is one KB of LDS per entry and block (terra_plan_fast_tree): a tree too deep for the LDS a block may ask for (clustered or
-    // coincident geometry under the device builder's Morton order can reach ~60 levels) cannot launch -- such a scene keeps the reference tree, which always fits
-    auto fast_stack_fits = [] ( int depth ) { return ( size_t ) ( depth + TERRA_FAST_STACK_AUX_KB ) * 1024 <= terra_lds_block_limit(); };
+    // the stack of a fast-tree launch keeps its first entries in LDS and the rest in HBM (terra_plan_fast_tree: 4 bytes per entry and resident lane), so depth is no longer
+    // a reason to give the fast tree up -- short of a degenerate tree whose worst case would ask for gigabytes of spill space
+    auto fast_stack_fits = [] ( int depth ) { return depth <= TERRA_FAST_STACK_MAX; };
     if ( s->use_fast && !s->fast_on_device && !fast_stack_fits ( s->fast_max_stack ) ) {
-        char b[200]; snprintf ( b, sizeof b, "fast tree needs a traversal stack of %d entries, more LDS than a block may hold: %s", s->fast_max_stack, s->cull_ok ? "reference tree with the leaf-box cull (global memory)" : "reference tree, replica traversal" );
-        s->use_fast = false; s->reach = false; s->tree_note = b; fnodes.clear(); ftris.clear(); soup_of_fast.clear(); s->fast_nodes = 0; s->fast_max_stack = 1;
+        char b[200]; snprintf ( b, sizeof b, "fast tree needs a traversal stack of %d entries (limit %d): %s", s->fast_max_stack, TERRA_FAST_STACK_MAX, s->cull_ok ? "reference tree with the leaf-box cull (global memory)" : "reference tree, replica traversal" );
+        s->use_fast = false; s->reach = false; s->tree_note = b; fnodes.clear(); fwide.nodes.clear(); ftris.clear(); soup_of_fast.clear(); s->fast_nodes = 0; s->fast_max_stack = 1;
     }
     if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : ( resident ? "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)" : s->tree_note );
     if ( s->reach && !s->fast_on_device ) build_reach_tables ( nodes, tris, soup_of_fast, reach_margin, reach_tabs );
@@ -903,8 +919,9 @@ static int upload_scene ( Scene* s ) {
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
     size_t o_mats = align ( o_props + props.size() * sizeof ( DevProps ) ), o_lights = align ( o_mats + mats.size() * sizeof ( DevMaterial ) );
     size_t o_area = align ( o_lights + lights.size() * sizeof ( DevLight ) ), o_fn = align ( o_area + tri_area.size() * sizeof ( float ) );
-    const size_t fn_cap = s->fast_on_device ? ntri : fnodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();      // a device build writes at most n - 1 nodes, n triangles
-    size_t o_fh = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_ft = align ( o_fh + fn_cap * sizeof ( DevFastNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );      // (o_fh: the nodes as traversed, DevFastNode)
+    // o_fn: the device builder's output (a binary tree of at most n - 1 nodes; host-built trees do not need it on the device), o_fh: the wide nodes the kernels traverse
+    const size_t fn_cap = s->fast_on_device ? ntri : 0, fh_cap = s->fast_on_device ? ntri : fwide.nodes.size(), ft_cap = s->fast_on_device ? ntri : ftris.size();
+    size_t o_fh = align ( o_fn + fn_cap * sizeof ( DevNode ) ), o_ft = align ( o_fh + fh_cap * sizeof ( DevFastNode ) ), o_td = align ( o_ft + ft_cap * sizeof ( DevTri ) );
     const size_t n_replay = s->reach ? ( nodes.size() ? nodes.size() : 1 ) : 0, n_reach_tri = s->reach ? ntri : 0;
     const size_t o_rp = o_td, o_lp = align ( o_rp + n_replay * sizeof ( DevReplay ) ), o_lm = align ( o_lp + n_reach_tri * 4 ); o_td = align ( o_lm + n_reach_tri * 4 );
     std::vector<DevTexture> tdesc ( textures.size() );
@@ -931,8 +948,8 @@ static int upload_scene ( Scene* s ) {
     HIP_TRY ( hipMemcpy ( base + o_mats, mats.data(), mats.size() * sizeof ( DevMaterial ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( base + o_lights, lights.data(), lights.size() * sizeof ( DevLight ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     HIP_TRY ( hipMemcpy ( base + o_area, tri_area.data(), tri_area.size() * sizeof ( float ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
-    if ( !fnodes.empty() ) {
-        HIP_TRY ( hipMemcpy ( base + o_fn, fnodes.data(), fnodes.size() * sizeof ( DevNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
+    if ( !fwide.nodes.empty() ) {
+        HIP_TRY ( hipMemcpy ( base + o_fh, fwide.nodes.data(), fwide.nodes.size() * sizeof ( DevFastNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
         HIP_TRY ( hipMemcpy ( base + o_ft, ftris.data(), ftris.size() * sizeof ( DevTri ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
     auto upload_reach_tables = [&] () -> int {
@@ -943,7 +960,7 @@ static int upload_scene ( Scene* s ) {
         return 0;
     };
     if ( s->reach && !s->fast_on_device ) { if ( int rc = upload_reach_tables() ) return rc; }
-    bool have_fast = !fnodes.empty();
+    bool have_fast = !fwide.nodes.empty();
     if ( s->fast_on_device ) {
         double t_phase = now_s();
         uint32_t* d_rank = nullptr;
@@ -954,14 +971,11 @@ static int upload_scene ( Scene* s ) {
         ( void ) hipFree ( d_rank );
         if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "device tree build: %s", hipGetErrorString ( e ) );
         phase ( "fast tree (device LBVH)", t_phase );
-        s->fast_nodes = built_nodes; s->fast_max_stack = built_stack; have_fast = true;
-        if ( !fast_stack_fits ( built_stack ) ) {          // (a Morton-ordered tree over clustered or coincident geometry can be ~60 levels deep)
-            char b[240]; snprintf ( b, sizeof b, "device-built fast tree needs a traversal stack of %d entries, more LDS than a block may hold: %s", built_stack, s->cull_ok ? "reference tree with the leaf-box cull (global memory)" : "reference tree, replica traversal" );
-            s->use_fast = false; s->reach = false; s->fast_on_device = false; s->tree_note = b; s->fast_nodes = 0; s->fast_max_stack = 1; have_fast = false;
-            if ( s->tree_mode == 2 && auto_ok && resident ) s->tree_note = "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
-        } else if ( s->tree_mode == 2 || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {          // the culling relies on containment: read the tree back and check it like the host-built one
-            std::vector<DevNode> rn ( built_nodes ); std::vector<DevTri> rt ( ntri );
-            HIP_TRY ( hipMemcpy ( rn.data(), base + o_fn, rn.size() * sizeof ( DevNode ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
+        // the binary tree comes back to the host: it is checked like a host-built one (automatic mode: the culling relies on containment) and made 4-wide there
+        std::vector<DevNode> rn ( built_nodes );
+        HIP_TRY ( hipMemcpy ( rn.data(), base + o_fn, rn.size() * sizeof ( DevNode ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
+        if ( s->tree_mode == 2 || s->reach || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {
+            std::vector<DevTri> rt ( ntri );
             HIP_TRY ( hipMemcpy ( rt.data(), base + o_ft, rt.size() * sizeof ( DevTri ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
             std::vector<TerraAABB> leaf_boxes ( ntri );
             for ( size_t k = 0; k < ntri; ++k ) {
@@ -980,17 +994,16 @@ static int upload_scene ( Scene* s ) {
                 phase ( "  reachability tables", t_phase );
             }
         }
+        fwide = fastbvh::widen ( rn, fast_scale );
+        phase ( "  4-wide binary16 nodes", t_phase );
+        s->fast_nodes = ( uint32_t ) fwide.nodes.size(); s->fast_max_stack = fwide.max_stack; have_fast = true;
+        if ( !fast_stack_fits ( fwide.max_stack ) ) {          // (a Morton-ordered tree over coincident geometry can be thousands of levels deep)
+            char b[240]; snprintf ( b, sizeof b, "device-built fast tree needs a traversal stack of %d entries (limit %d): %s", fwide.max_stack, TERRA_FAST_STACK_MAX, s->cull_ok ? "reference tree with the leaf-box cull (global memory)" : "reference tree, replica traversal" );
+            s->use_fast = false; s->reach = false; s->fast_on_device = false; s->tree_note = b; s->fast_nodes = 0; s->fast_max_stack = 1; have_fast = false;
+            if ( s->tree_mode == 2 && auto_ok && resident ) s->tree_note = "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
+        } else HIP_TRY ( hipMemcpy ( base + o_fh, fwide.nodes.data(), fwide.nodes.size() * sizeof ( DevFastNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
-    float fast_scale = 1.f;
-    if ( have_fast && s->fast_nodes ) {       // boxes as binary16 planes (DevFastNode): what the kernels traverse; everything above checked the (min, max) form
-        // every plane times a power of two that brings the largest of them (|coordinate| + box margin) below 2^14: binary16 reaches 65,504, and a power of two changes
-        // no bit of plane or t value -- the kernel divides the ray's inverse direction by the same factor (DevScene::fast_inv_scale)
-        const float reach = s->coord_max + 1e-4f + fast_extra;
-        if ( std::isfinite ( reach ) ) while ( reach * fast_scale >= 16384.f && fast_scale > 0x1p-100f ) fast_scale *= 0.5f;
-        if ( s->fast_nodes >= ( 1u << 27 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address nodes by a 32-bit byte offset (at most 2^27 nodes)", s->fast_nodes );
-        hipError_t e = terra_fast_nodes_half_planes ( ( const DevNode* ) ( base + o_fn ), s->fast_nodes, fast_scale, ( DevFastNode* ) ( base + o_fh ), nullptr );
-        if ( e != hipSuccess ) return fail ( kTerraAmdErrLaunch, "fast tree conversion: %s", hipGetErrorString ( e ) );
-    }
+    if ( have_fast && s->fast_nodes >= ( 1u << 26 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address nodes by a 32-bit byte offset (at most 2^26 nodes)", s->fast_nodes );
     for ( size_t k = 0; k < textures.size(); ++k ) {
         const TerraTexture* t = textures[k];
         HIP_TRY ( hipMemcpy ( base + tex_off[k], t->pixels, ( size_t ) t->width * t->height * t->components * t->depth, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
@@ -1004,7 +1017,7 @@ static int upload_scene ( Scene* s ) {
     s->dev.mats = ( const DevMaterial* ) ( base + o_mats ); s->dev.lights = ( const DevLight* ) ( base + o_lights ); s->dev.tri_area = ( const float* ) ( base + o_area );
     s->dev.n_nodes = ( uint32_t ) nodes.size(); s->dev.n_tris = ( uint32_t ) ntri; s->dev.n_objects = ( uint32_t ) nobj; s->dev.n_lights = ( uint32_t ) s->lights.size();
     s->dev.lights_triangles_count = ( uint32_t ) s->lights_triangles_count; s->dev.max_stack = s->max_stack;
-    s->dev.fast_nodes = have_fast ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_nodes_h = have_fast ? ( const DevFastNode* ) ( base + o_fh ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
+    s->dev.fast_nodes = ( have_fast && s->fast_on_device ) ? ( const DevNode* ) ( base + o_fn ) : nullptr; s->dev.fast_nodes_h = have_fast ? ( const DevFastNode* ) ( base + o_fh ) : nullptr; s->dev.fast_tris = have_fast ? ( const DevTri* ) ( base + o_ft ) : nullptr;
     s->dev.n_fast_nodes = s->fast_nodes; s->dev.fast_max_stack = s->fast_max_stack; s->dev.fast_inv_scale = 1.f / fast_scale;
     s->dev.reach = ( s->reach && have_fast && !reach_tabs.leaf_parent.empty() ) ? 1u : 0u;
     s->dev.ref_replay = s->dev.reach ? ( const DevReplay* ) ( base + o_rp ) : nullptr; s->dev.fast_leaf_parent = s->dev.reach ? ( const uint32_t* ) ( base + o_lp ) : nullptr; s->dev.fast_leaf_mask = s->dev.reach ? ( const uint32_t* ) ( base + o_lm ) : nullptr;
@@ -1152,7 +1165,7 @@ extern "C" int terra_amd_get_stats ( HTerraScene h, TerraAmdStats* out ) {
     out->rays = c[kCtrRays]; out->nodes = c[kCtrNodes]; out->tri_tests = c[kCtrTriTests]; out->hits = c[kCtrHits];
     out->rand_calls = c[kCtrRandCalls]; out->attr_fetches = c[kCtrAttrFetches]; out->tri_culled = c[kCtrTriCulled];
     // derived exactly on the host (see Counters in trace_device.h)
-    out->box_tests = s->dev.n_tris >= 2 ? ( s->cull_ok && !s->use_fast ? 2 * out->nodes : 2 * out->nodes - out->tri_tests ) : 0;      // with the leaf-box cull every child's slab test is used
+    out->box_tests = s->dev.n_tris >= 2 ? ( s->use_fast ? 4 * out->nodes : s->cull_ok ? 2 * out->nodes : 2 * out->nodes - out->tri_tests ) : 0;      // the fast tree's nodes hold four boxes; with the leaf-box cull every child's slab test is used
     out->samples = s->stat_samples; out->pixels = s->stat_pixels; out->launches = s->launches;
     return 0;
 }
@@ -1231,7 +1244,11 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     terra_plan_lds ( p );
     // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
     const bool cam_ok = ( s->reach || s->reach_cull ) ? ( fabsf ( p.cam_pos[0] ) <= s->reach_limit && fabsf ( p.cam_pos[1] ) <= s->reach_limit && fabsf ( p.cam_pos[2] ) <= s->reach_limit ) : coords_within_margin ( p.cam_pos, 3 );
-    if ( s->use_fast && s->dev.fast_nodes && ( s->tree_mode == 1 || cam_ok ) ) terra_plan_fast_tree ( p );
+    if ( s->use_fast && s->dev.fast_nodes_h && ( s->tree_mode == 1 || cam_ok ) ) terra_plan_fast_tree ( p );
+    if ( s->test_fast_stack_lds > 0 && p.lds_mode == 2 ) {      // TEST HOOK: a short LDS column, so that ordinary scenes exercise the HBM part of the stack
+        const uint32_t need = p.stack_depth + p.spill_cap;
+        p.stack_depth = need < ( uint32_t ) s->test_fast_stack_lds ? need : ( uint32_t ) s->test_fast_stack_lds; p.spill_cap = need - p.stack_depth;
+    }
     if ( s->test_pad_stack > 0 && p.lds_mode != 1 ) {          // TEST HOOK: a deeper stack than the tree needs (the LDS-resident plan is sized to the byte and stays as it is)
         p.stack_depth += ( uint32_t ) s->test_pad_stack;
         while ( p.leaf_cap > 4 && terra_lds_bytes ( p ) > ( size_t ) 64 * 1024 ) --p.leaf_cap;      // (what terra_plan_lds does for a deep tree)
@@ -1240,7 +1257,10 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     p.fused_slab = ( p.leaf_cull && !s->reach_cull ) ? 1u : 0u;      // (out of range only the rebuilt LEAF boxes carry a margin: the inner boxes are tested exactly as the reference tests them)
     // the azimuth table pays where VALU issue binds (LDS-resident scenes: Cornell Simple 65.8 -> 64.2 ms, Direct 145.2 -> 142.5); the kernels that wait on memory anyway
     // lose by one more dependent load per shaded hit (sphere scene 395 -> 419 ms, hall 282 -> 284; profiles/r03_measurements/ab_sincos_table.log)
-    if ( p.lds_mode != 1 ) p.scene.sincos24 = nullptr;
+#ifndef TERRA_SINCOS_TABLE_FAST_TREE       // (A/B) the azimuth table for fast-tree launches too
+#define TERRA_SINCOS_TABLE_FAST_TREE 0
+#endif
+    if ( p.lds_mode != 1 && ! ( TERRA_SINCOS_TABLE_FAST_TREE && p.lds_mode == 2 ) ) p.scene.sincos24 = nullptr;
     // what this call runs (TerraAmdTraversalInfo::last_call): the commit-time decision can be overridden per call by the camera position
     s->last_call.store ( p.lds_mode == 2 ? ( s->dev.reach ? kTerraAmdCallFastTreeReach : kTerraAmdCallFastTree ) : ( p.leaf_cull ? kTerraAmdCallLeafCull : kTerraAmdCallReplica ), std::memory_order_relaxed );
     p.bsdf_kinds = s->bsdf_kinds;
@@ -1302,7 +1322,8 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     p.job_blocks = blocks * split;
     const size_t stream_bytes = terra_job_streams_bytes ( p );
     if ( stream_bytes && ( p.fb_w > 65535u || p.fb_h > 65535u ) ) return fail ( kTerraAmdErrBadArgument, "framebuffer of %u x %u: at most 65,535 pixels per side (the job table packs a pixel into 32 bits)", p.fb_w, p.fb_h );
-    const size_t scratch_bytes = header + partial_bytes + stream_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)]
+    const size_t spill_bytes = terra_fast_spill_bytes ( p );                 // fast-tree launches: the part of the lanes' traversal stacks that does not live in LDS
+    const size_t scratch_bytes = header + partial_bytes + stream_bytes + spill_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)][stack spill (fast tree)]
     // (a thread's slot keeps scratch for tile-sized calls only: a full-frame call's gigabytes come from, and go back to, the device's pool)
     void* scratch = ( slot && scratch_bytes <= ( size_t ( 256 ) << 20 ) ) ? slot_scratch ( slot, scratch_bytes ) : nullptr;
     const bool pooled = scratch == nullptr;
@@ -1314,6 +1335,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     p.chunk_spp = p.spp / split; p.partials = ( float4* ) ( ( char* ) scratch + header );
     p.job_blocks = blocks * split; p.job_queue = terra_render_wants_queue ( p ) ? ( uint32_t* ) scratch : nullptr;
     p.job_streams = stream_bytes ? ( uint4* ) ( ( char* ) scratch + header + partial_bytes ) : nullptr;
+    p.stack_spill = spill_bytes ? ( uint32_t* ) ( ( char* ) scratch + header + partial_bytes + stream_bytes ) : nullptr;
     {   // the job decode divides block numbers by launch constants: as multiplications by ceil(2^32 / d), exact while (largest dividend) * divisor < 2^32
         const uint64_t bpt = p.tile_size / 16, bpt2 = bpt * bpt, tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size, tiles_y = ( p.h + p.tile_size - 1 ) / p.tile_size;
         auto magic = [] ( uint64_t d ) { return d <= 1 ? 0u : ( uint32_t ) ( ( ( 1ull << 32 ) + d - 1 ) / d ); };
@@ -1692,7 +1714,7 @@ extern "C" int terra_amd_unit_bvh_traverse ( HTerraScene hs, int n, const float*
 }
 extern "C" int terra_amd_unit_bvh_traverse_fast ( HTerraScene hs, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point3, uint32_t* nodes_visited ) {
     Scene* s = S ( hs ); int rc = need_scene ( s ); if ( rc ) return rc;
-    if ( !s->dev.fast_nodes ) return fail ( kTerraAmdErrBadArgument, "the committed scene has no fast tree (terra_amd_set_tree_mode 1, or 2 on a scene that is not LDS-resident)" );
+    if ( !s->dev.fast_nodes_h ) return fail ( kTerraAmdErrBadArgument, "the committed scene has no fast tree (terra_amd_set_tree_mode 1, or 2 on a scene that is not LDS-resident)" );
     Unit u; auto a = u.in ( o, 3 * ( size_t ) n ); auto b = u.in ( d, 3 * ( size_t ) n );
     auto f = u.out ( found, n ); auto pr = u.out ( prim, n ); auto pt = u.out ( point3, 3 * ( size_t ) n ); auto nv = u.out ( nodes_visited, n );
     return u.finish ( u.ok ? terra_unit_bvh_traverse_fast ( s->dev, n, a, b, f, pr, pt, nv ) : hipSuccess );
@@ -1739,6 +1761,13 @@ extern "C" int terra_amd_unit_math ( int fn, int n, const float* x, const float*
     if ( need_device() ) return kTerraAmdErrNoDevice;
     Unit u; auto a = u.in ( x, n ); auto b = u.in ( y ? y : x, n ); auto o = u.out ( out, n );
     return u.finish ( u.ok ? terra_unit_math ( fn, n, a, b, o ) : hipSuccess );
+}
+
+// binary16 planes of the fast tree's nodes (tree_build.cpp fastbvh::half_outward): host arithmetic, no device needed
+extern "C" int terra_amd_unit_half_outward ( const double* x, int n, int up, uint16_t* out ) {
+    if ( n < 0 || ( n && ( !x || !out ) ) ) return fail ( kTerraAmdErrBadArgument, "null array" );
+    for ( int i = 0; i < n; ++i ) out[i] = fastbvh::half_outward ( x[i], up != 0 );
+    return 0;
 }
 
 // ---- SURVEY.md 8f N4, unit level (reference src/Terra.c:703-755, 760-846) ------------------------------------------------------

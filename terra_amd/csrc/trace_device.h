@@ -242,6 +242,10 @@ struct Tracer {
     int*          leaves;
     int           leaf_cap;    // entries in the leaf list (>= 2)
     int           stack_cap;   // entries in the stack column (TERRA_CHECK_BOUNDS builds verify every push against it)
+    // fast-tree launches: entries beyond the LDS column live in HBM (DevRenderParams::stack_spill): spill = this lane's spill_cap words, nullptr when the column holds the whole stack
+    uint32_t      stack_lim;   // 32-bit LDS address of the block's stack words + stack entries * 1024: wave-uniform (fast_push / fast_pop)
+    uint32_t*     spill;
+    uint32_t      spill_cap;
     unsigned long long* faults;
     // leaf-box cull (DESIGN.md "Leaf-box cull"): a leaf child's triangle is tested only if the ray passes the slab test of
     // that child's box -- the box the node already carries and the node step already tests. The reference tests the triangle
@@ -487,16 +491,18 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 // (DevTri::pad of the fast soup). The triangle test itself is the same arithmetic.
 // Child word of a fast node: bit 31 leaf; leaf = (count-1) << 27 | first triangle.
 //
-// Node format in HBM (DevFastNode, 32 B; written from the builder's (min, max) node by tree_build_device.hip tb_half_planes_kernel): the twelve planes of the two
-// child boxes as binary16, rounded OUTWARD, one 32-bit word (min | max << 16) per child and axis, then the two child words: TWO 16-byte loads fetch a node.
-// The render kernels of scenes read from global memory are bound by the texture addresser (profiles/r04_*: TA busy 99 % of the kernel's cycles, ~21 of its cycles per
-// wave-level load instruction whatever the instruction's width), so what counts is the NUMBER of load instructions per ray, not their bytes: the 64-byte (min, max)
-// node of rounds 2-3 took four. Per axis the ray swaps the halves of a word when it travels in the negative direction (one v_perm_b32 with a per-ray selector), so
-// that the low half is the near plane and the high half the far one; each plane then goes straight into t = fma ( plane, inv, -(o * inv) ) as the binary16 operand
-// of v_fma_mix_f32: a box costs three swaps, six fused multiply-adds, a v_max3, a v_min3 and the comparisons. Unlike the reference tree's test this one only has to
-// be CONSERVATIVE (never reject a box that holds a triangle the ray hits; DESIGN.md "Traversal policy"): rounding the planes outward only widens the box, and t
-// carries two roundings (o * inv, the fma) where the commit-time error budget (scene_host.cpp "numeric containment check") allows four. Planes are stored times
-// DevScene::fast_scale (a power of two: exact) so that every scene fits binary16's range; the ray's inverse direction is divided by it (exact too).
+// Node format in HBM (DevFastNode, 64 B, FOUR children; made on the host by tree_build.cpp fastbvh::widen): the planes of the child boxes as binary16, rounded
+// OUTWARD, one 32-bit word (min | max << 16) per child and axis, then the four child words: four 16-byte loads fetch a node.
+// What binds the render kernels of scenes read from global memory (profiles/r04_measurements/ab_fast_node_formats.log): (1) the texture addresser -- ~21-27 of its
+// cycles per wave-level load instruction whatever the instruction's width, 99 % busy when a node step issues 4 loads for 2 boxes -- so what counts is the NUMBER of
+// load instructions per ray, not their bytes; (2) the dependent chain: a ray's node fetches follow one another, and the waves spend 54 % of their cycles waiting.
+// A 4-wide node of binary16 planes answers both: 4 loads bring 4 boxes (the 64-byte (min, max) node of rounds 2-3 brought 2), and a ray needs half as many round trips.
+// Per axis the ray swaps the halves of a plane word when it travels in the negative direction (one v_perm_b32 with a per-ray selector), so that the low half is the
+// near plane and the high half the far one; each plane then goes straight into t = fma ( plane, inv, -(o * inv) ) as the binary16 operand of v_fma_mix_f32: a box
+// costs three swaps, six fused multiply-adds, a v_max3, a v_min3 and the comparisons. Unlike the reference tree's test this one only has to be CONSERVATIVE (never
+// reject a box that holds a triangle the ray hits; DESIGN.md "Traversal policy"): rounding the planes outward only widens the box, and t carries two roundings
+// (o * inv, the fma) where the commit-time error budget (scene_host.cpp "numeric containment check") allows four. Planes are stored times DevScene::fast_scale (a
+// power of two: exact) so that every scene fits binary16's range; the ray's inverse direction is divided by it (exact too).
 // An empty child slot is an inverted box (min = +max_half, max = -max_half): never entered, so no lane ever holds it.
 // -----------------------------------------------------------------------------
 typedef _Float16 terra_half2 __attribute__ (( ext_vector_type ( 2 ) ));
@@ -557,26 +563,52 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
     return ok;
 }
 
-// The far child of a node whose two boxes are hit waits on the lane's stack (LDS); the near one stays in a register (`cur`) --
-// or, when it is a leaf, goes straight into `leaf`: a lane that has a leaf in hand HOLDS it. Each iteration the wave votes: while
-// fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and some lane can still descend) the descending lanes take
-// a node step, otherwise the holders test one triangle each. (16/16 is the classic "while-while" loop: descend until every lane
-// holds a leaf.) The vote trades a fuller node step -- 6 x more executions than triangle steps on the hall -- against an emptier
-// triangle step.
-// The traversal is resumable (stack column in LDS; top, held leaf, closest hit in registers): it returns as soon as the
+// Of the children of a node whose boxes the ray enters, the nearest stays in a register (`cur`) -- or, when it is a leaf, goes straight into `leaf`: a lane that has
+// a leaf in hand HOLDS it -- and the others wait on the lane's stack, farthest first. The stack's first entries are an LDS column, the rest -- which a ray almost
+// never reaches: the column covers the depths rays actually see, the bound is the tree's worst case -- a few words of HBM per lane (fast_push / fast_pop).
+// Each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and some lane can still descend) the descending lanes
+// take a node step, otherwise the holders test one triangle each. (16/16 is the classic "while-while" loop: descend until every lane holds a leaf.) The vote
+// trades a fuller node step against an emptier triangle step.
+// The traversal is resumable (stack in LDS / HBM; top, held leaf, closest hit in registers): it returns as soon as the
 // number of lanes still traversing has dropped to `exit_active`, so the render loop can shade the finished lanes and hand
 // them their next ray (exit_active = 0: run every lane's ray to the end). `traversing` is cleared for lanes whose traversal
 // completed. What a lane computes, and in which order, does not depend on the votes.
 #ifndef TERRA_FAST_LEAF_16THS
 #define TERRA_FAST_LEAF_16THS 8
 #endif
+#ifndef TERRA_FAST_SORT            // 1: the entered children of a node are visited nearest first (sorting network); 0: nearest first, the rest in slot order (A/B)
+#define TERRA_FAST_SORT 1
+#endif
+// (the test "is this entry in the LDS column" compares the entry's 32-bit LDS address with ONE wave-uniform limit: entry e of thread t sits at column base + e * 1024 + t * 4,
+//  and t * 4 < 1024, so address < base + cap * 1024 exactly when e < cap; the HBM index is computed on the cold side only)
+TD void fast_push ( const Tracer& T, int*& top, uint32_t v ) {
+    const uint32_t a = ( uint32_t ) ( uintptr_t ) top;
+    if ( __builtin_expect ( a < T.stack_lim, 1 ) ) *top = ( int ) v;
+    else {
+        const uint32_t k = ( a - T.stack_lim ) >> 10;
+        if ( TERRA_CHECK_BOUNDS && ( !T.spill || k >= T.spill_cap ) ) { if ( T.faults ) atomicAdd ( T.faults, 1ull ); return; }
+        T.spill[k] = v;
+    }
+    top += TERRA_COL;
+}
+TD uint32_t fast_pop ( const Tracer& T, int*& top ) {
+    top -= TERRA_COL;
+    const uint32_t a = ( uint32_t ) ( uintptr_t ) top;
+    return __builtin_expect ( a < T.stack_lim, 1 ) ? ( uint32_t ) * top : T.spill[ ( a - T.stack_lim ) >> 10];
+}
+// compare-exchange of two (key, child word) pairs: afterwards a holds the smaller key
+TD void order_pair ( uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb ) {
+    const bool swap = kb < ka;
+    const uint32_t k0 = swap ? kb : ka, k1 = swap ? ka : kb, c0 = swap ? cb : ca, c1 = swap ? ca : cb;
+    ka = k0; kb = k1; ca = c0; cb = c1;
+}
 template <int COUNT>
 TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c, bool checked = false ) {
     const FastRay f = fast_ray ( ray, T.sc.fast_inv_scale );
     const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes_h );
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
-    // `cur`: the node a lane descends into next stays in a register (the near child when both are hit); only the far child
-    // goes through the stack, so a descent step does not wait for an LDS write + read of its own
+    // `cur`: the node a lane descends into next stays in a register (the nearest child entered); only the others
+    // go through the stack, so a descent step does not wait for an LDS write + read of its own
     uint32_t cur = DEV_CHILD_EMPTY;
     for ( ;; ) {
         const bool holder = traversing && leaf != 0;
@@ -588,29 +620,37 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             if ( can ) {
                 PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
                 uint32_t w = cur;
-                if ( w == DEV_CHILD_EMPTY ) { top -= TERRA_COL; w = ( uint32_t ) * top; }
+                if ( w == DEV_CHILD_EMPTY ) w = fast_pop ( T, top );
                 cur = DEV_CHILD_EMPTY;
-                if ( w & DEV_CHILD_LEAF ) leaf = w;                  // (a far child that was a leaf comes off the stack)
+                if ( w & DEV_CHILD_LEAF ) leaf = w;                  // (a leaf that waited on the stack)
                 else {
-                    const uint32_t off = w << 5;
-                    const uint4 q0 = *reinterpret_cast<const uint4*> ( nodes + off ), q1 = *reinterpret_cast<const uint4*> ( nodes + ( off + 16u ) );      // {x0 y0 z0 x1} {y1 z1 child0 child1}
-                    const uint2 ch = make_uint2 ( q1.z, q1.w );
+                    const uint32_t off = w << 6;
+                    const uint4 q0 = *reinterpret_cast<const uint4*> ( nodes + off ), q1 = *reinterpret_cast<const uint4*> ( nodes + ( off + 16u ) ),
+                                q2 = *reinterpret_cast<const uint4*> ( nodes + ( off + 32u ) ), ch = *reinterpret_cast<const uint4*> ( nodes + ( off + 48u ) );      // {x0 y0 z0 x1} {y1 z1 x2 y2} {z2 x3 y3 z3} {children}
                     if ( COUNT ) ++c.nodes;
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
-                    float te0, te1;
+                    float te0, te1, te2, te3;
                     const bool hit0 = slab_half ( q0.x, q0.y, q0.z, f, te0 ) && te0 <= best.depth;
                     const bool hit1 = slab_half ( q0.w, q1.x, q1.y, f, te1 ) && te1 <= best.depth;
-                    const bool one_near = hit1 && ! ( hit0 && te0 <= te1 );          // child 1 is the one to enter first
-                    const uint32_t near = one_near ? ch.y : ch.x, far = one_near ? ch.x : ch.y;
-                    if ( hit0 && hit1 ) {
-                        TERRA_PUSH ( T, top, far );
-#if TERRA_PHASE_STATS
-                        { const int dpt = ( int ) ( top - T.stack ) / TERRA_COL; ++c.ps[kPsCamLanes]; c.ps[kPsShadeIter] += dpt >= 4; c.ps[kPsRayLanes] += dpt >= 6; c.ps[kPsCamIter] += dpt >= 8; c.ps[kPsDrainIter] += dpt >= 10; c.ps[kPsShadeLanes] += dpt >= 12; }
+                    const bool hit2 = slab_half ( q1.z, q1.w, q2.x, f, te2 ) && te2 <= best.depth;
+                    const bool hit3 = slab_half ( q2.y, q2.z, q2.w, f, te3 ) && te3 <= best.depth;
+                    // nearest first: the entry distances (>= 0, so their bit patterns order like the floats) sorted with their child words; a box not entered sorts last
+                    uint32_t k0 = hit0 ? __float_as_uint ( te0 ) : 0xffffffffu, k1 = hit1 ? __float_as_uint ( te1 ) : 0xffffffffu, k2 = hit2 ? __float_as_uint ( te2 ) : 0xffffffffu, k3 = hit3 ? __float_as_uint ( te3 ) : 0xffffffffu;
+                    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#if TERRA_FAST_SORT
+                    order_pair ( k0, c0, k1, c1 ); order_pair ( k2, c2, k3, c3 ); order_pair ( k0, c0, k2, c2 ); order_pair ( k1, c1, k3, c3 ); order_pair ( k1, c1, k2, c2 );
+#else               // (A/B) only the nearest is found; the others go on the stack in slot order
+                    order_pair ( k0, c0, k1, c1 ); order_pair ( k0, c0, k2, c2 ); order_pair ( k0, c0, k3, c3 );
 #endif
-                    }
-                    if ( hit0 || hit1 ) { if ( near & DEV_CHILD_LEAF ) leaf = near; else cur = near; }
+                    if ( k3 != 0xffffffffu ) fast_push ( T, top, c3 );          // the farthest goes in first, so the nearer ones come off first
+                    if ( k2 != 0xffffffffu ) fast_push ( T, top, c2 );
+                    if ( k1 != 0xffffffffu ) fast_push ( T, top, c1 );
+#if TERRA_PHASE_STATS
+                    if ( k1 != 0xffffffffu ) { const int dpt = ( int ) ( top - T.stack ) / TERRA_COL; ++c.ps[kPsCamLanes]; c.ps[kPsShadeIter] += dpt >= 4; c.ps[kPsRayLanes] += dpt >= 6; c.ps[kPsCamIter] += dpt >= 8; c.ps[kPsDrainIter] += dpt >= 12; c.ps[kPsShadeLanes] += dpt >= 16; }
+#endif
+                    if ( k0 != 0xffffffffu ) { if ( c0 & DEV_CHILD_LEAF ) leaf = c0; else cur = c0; }
                 }
             }
         } else if ( holder ) {
@@ -632,7 +672,7 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             }
         }
     }
-    if ( cur != DEV_CHILD_EMPTY ) { TERRA_PUSH ( T, top, cur ); }      // leaving with a node in hand: it waits on the stack
+    if ( cur != DEV_CHILD_EMPTY ) fast_push ( T, top, cur );      // leaving with a node in hand: it waits on the stack
 }
 
 // REACH = false: the kernels launched for scenes inside the coordinate range (template MODE 2) carry none of the replay code; MODE 3 = the same loops with it

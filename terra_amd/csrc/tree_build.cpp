@@ -351,4 +351,81 @@ Built build ( std::vector<Prim>& prims ) {
     for ( int i = 0; i < n; ++i ) out.order[ ( size_t ) i] = prims[ ( size_t ) i].soup;
     return out;
 }
+
+// ---- binary16 with directed rounding ---------------------------------------------------------------------------------------------
+// x -> binary16 bits, rounded towards -inf (up = false) or +inf (up = true): integer arithmetic on the double's bits, no dependence on the host's half support.
+// Magnitudes beyond 65504 give +-65504 when rounding towards zero and +-inf when rounding away (a wider box, never a narrower one); NaN gives the widest value too.
+uint16_t half_outward ( double x, bool up ) {
+    uint64_t u; memcpy ( &u, &x, 8 );
+    const bool neg = ( u >> 63 ) != 0;
+    const uint16_t sign = neg ? 0x8000u : 0u;
+    const int e11 = ( int ) ( ( u >> 52 ) & 0x7ff );
+    const uint64_t m52 = u & ( ( 1ull << 52 ) - 1 );
+    const bool away = neg ? !up : up;                                       // the magnitude is rounded away from zero
+    if ( e11 == 0x7ff ) return m52 ? ( up ? 0x7c00u : 0xfc00u ) : ( uint16_t ) ( sign | 0x7c00u );      // NaN: +inf as an upper bound, -inf as a lower one; inf: itself
+    if ( e11 == 0 ) return ( m52 && away ) ? ( uint16_t ) ( sign | 1u ) : sign;                          // zero / double subnormal (below every binary16 subnormal)
+    const int e = e11 - 1023 + 15;                                          // binary16 biased exponent
+    if ( e >= 31 ) return ( uint16_t ) ( sign | ( away ? 0x7c00u : 0x7bffu ) );
+    uint32_t h; bool inexact;
+    if ( e >= 1 ) { h = ( ( uint32_t ) e << 10 ) | ( uint32_t ) ( m52 >> 42 ); inexact = ( m52 & ( ( 1ull << 42 ) - 1 ) ) != 0; }
+    else {
+        const int sh = 42 + ( 1 - e );                                      // binary16 subnormal: shift the significand (with its leading 1) further right
+        const uint64_t full = ( 1ull << 52 ) | m52;
+        if ( sh >= 64 ) { h = 0; inexact = true; }
+        else { h = ( uint32_t ) ( full >> sh ); inexact = ( full & ( ( 1ull << sh ) - 1 ) ) != 0; }
+    }
+    if ( inexact && away ) ++h;                                             // (a carry out of the mantissa moves into the exponent: the next power of two, or inf)
+    return ( uint16_t ) ( sign | h );
+}
+
+// ---- the binary tree as 4-wide binary16 nodes -------------------------------------------------------------------------------------
+Wide widen ( const std::vector<DevNode>& n2, float scale ) {
+    Wide out;
+    struct Slot { float mn[3], mx[3]; uint32_t word; };
+    auto slot_of = [&] ( const DevNode & nd, int k ) { Slot s; memcpy ( s.mn, k ? nd.min1 : nd.min0, 12 ); memcpy ( s.mx, k ? nd.max1 : nd.max0, 12 ); s.word = nd.child[k]; return s; };
+    auto inner = [] ( uint32_t w ) { return w != DEV_CHILD_EMPTY && ! ( w & DEV_CHILD_LEAF ); };
+    auto area = [] ( const Slot & s ) { const float w = s.mx[0] - s.mn[0], h = s.mx[1] - s.mn[1], d = s.mx[2] - s.mn[2]; return w * h + h * d + d * w; };
+    if ( n2.empty() ) return out;
+    // wide node i is made from binary node src[i]; children get consecutive indices when their parent is made (siblings share cache lines), subtrees follow depth first
+    std::vector<uint32_t> src; src.push_back ( 0 );
+    std::vector<uint32_t> todo; todo.push_back ( 0 );
+    std::vector<int> kids;                       // per wide node: children in use (for the stack bound below)
+    out.nodes.push_back ( DevFastNode() ); kids.push_back ( 0 );
+    while ( !todo.empty() ) {
+        const uint32_t wi = todo.back(); todo.pop_back();
+        Slot slots[4]; int n = 0;
+        for ( int k = 0; k < 2; ++k ) if ( n2[src[wi]].child[k] != DEV_CHILD_EMPTY ) slots[n++] = slot_of ( n2[src[wi]], k );
+        while ( n < 4 ) {
+            int pick = -1; float best = -1.f;
+            for ( int k = 0; k < n; ++k ) if ( inner ( slots[k].word ) ) { const DevNode& c = n2[slots[k].word]; if ( c.child[0] == DEV_CHILD_EMPTY || c.child[1] == DEV_CHILD_EMPTY ) continue; const float a = area ( slots[k] ); if ( a > best ) { best = a; pick = k; } }
+            if ( pick < 0 ) break;
+            const DevNode& c = n2[slots[pick].word];
+            slots[pick] = slot_of ( c, 0 ); slots[n++] = slot_of ( c, 1 );
+        }
+        DevFastNode nd;
+        for ( int k = 0; k < 4; ++k ) {
+            if ( k >= n ) { for ( int a = 0; a < 3; ++a ) nd.p[k][a] = 0x7bffu | ( 0xfbffu << 16 ); nd.child[k] = DEV_CHILD_EMPTY; continue; }      // an empty slot: min = +65504, max = -65504 -- no ray enters it
+            for ( int a = 0; a < 3; ++a ) {
+                const bool empty = ! ( slots[k].mn[a] <= slots[k].mx[a] );
+                const uint32_t lo = empty ? 0x7bffu : half_outward ( ( double ) slots[k].mn[a] * ( double ) scale, false ), hi = empty ? 0xfbffu : half_outward ( ( double ) slots[k].mx[a] * ( double ) scale, true );
+                nd.p[k][a] = lo | ( hi << 16 );
+            }
+            if ( inner ( slots[k].word ) ) { nd.child[k] = ( uint32_t ) src.size(); src.push_back ( slots[k].word ); out.nodes.push_back ( DevFastNode() ); kids.push_back ( 0 ); }
+            else nd.child[k] = slots[k].word;
+        }
+        kids[wi] = n;
+        out.nodes[wi] = nd;
+        for ( int k = n - 1; k >= 0; --k ) if ( ! ( nd.child[k] & DEV_CHILD_LEAF ) ) todo.push_back ( nd.child[k] );
+    }
+    // stack entries a ray can need: a node with k children in use leaves up to k - 1 of them pending while the traversal is below one of them; + the root's own entry
+    // and the node a lane has in hand when it leaves the loop. Children have larger indices than their parent, so one backward sweep does it.
+    std::vector<int> need ( out.nodes.size(), 0 );
+    for ( size_t i = out.nodes.size(); i-- > 0; ) {
+        int below = 0;
+        for ( int k = 0; k < 4; ++k ) { const uint32_t w = out.nodes[i].child[k]; if ( w != DEV_CHILD_EMPTY && ! ( w & DEV_CHILD_LEAF ) ) below = std::max ( below, need[w] ); }
+        need[i] = std::max ( 0, kids[i] - 1 ) + below;
+    }
+    out.max_stack = need[0] + 2;
+    return out;
+}
 } // namespace fastbvh

@@ -21,4 +21,11 @@ namespace fastbvh {
 struct Prim { TerraAABB box; float c[3]; uint32_t soup; };
 struct Built { std::vector<DevNode> nodes; std::vector<uint32_t> order; int max_stack = 1; };
 Built build ( std::vector<Prim>& prims );      // reorders prims into leaf order
+// The tree as the kernels traverse it: 4-wide nodes of binary16 planes (dev_types.h DevFastNode). `nodes2` is a binary tree in the builders' output form ((min, max)
+// child boxes, root at 0, leaf word = DEV_CHILD_LEAF | (count - 1) << 27 | first), built on the host (above) or read back from the device builder. A wide node
+// takes the two children of a binary node and, while it has fewer than four, replaces the inner child with the largest box by that child's two children; every plane
+// is multiplied by `scale` (a power of two) and rounded OUTWARD to binary16, so each wide child box contains the binary tree's box of the same subtree.
+struct Wide { std::vector<DevFastNode> nodes; int max_stack = 1; };
+Wide widen ( const std::vector<DevNode>& nodes2, float scale );
+uint16_t half_outward ( double x, bool up );      // the largest binary16 <= x (up = false) or the smallest >= x (up = true), as bits
 }

@@ -215,49 +215,3 @@ hipError_t terra_build_fast_tree_device ( const DevTri* tris, const uint32_t* ra
     *max_stack_out = ( int ) depth + 1;             // one pending (far) child per level + the node in hand when a lane leaves the loop (as fastbvh::build)
     return hipSuccess;
 }
-
-// -----------------------------------------------------------------------------
-// Traversal form of a fast-tree node (dev_types.h DevFastNode, 32 B; the traversal is trace_device.h traverse_fast_resume): each child
-// box (min, max) becomes six binary16 planes, times `scale` (a power of two chosen by the host so that every plane fits binary16's
-// range), rounded OUTWARD -- min down, max up. The new box CONTAINS the old one, which is all the fast tree's traversal needs
-// (DESIGN.md "Traversal policy"); the commit-time containment check runs on the (min, max) boxes before this.
-// -----------------------------------------------------------------------------
-// x -> the largest binary16 <= x (DOWN) or the smallest >= x (up), as bits. HIP's __float2half_rd / _ru are not relied upon (their rounding is not
-// pinned across ROCm releases): round to nearest, then step one binary16 towards the wanted side if that went the wrong way. +-inf results are fine (wider).
-template <bool DOWN>
-__device__ __forceinline__ uint16_t half_outward ( double x ) {      // (a double: plane x scale is exact in it whatever the scale)
-    const _Float16 h = ( _Float16 ) ( float ) x;
-    uint16_t u = __builtin_bit_cast ( uint16_t, h );
-    const double b = ( double ) ( float ) h;
-    if ( DOWN ? b > x : b < x ) {
-        const bool away = DOWN ? ( u & 0x8000u ) != 0 : ( u & 0x8000u ) == 0;      // the step goes away from zero: one more in magnitude
-        if ( ( u & 0x7fffu ) == 0 ) u = DOWN ? 0x8001u : 0x0001u;                   // from +-0 to the smallest subnormal of the wanted sign
-        else u = away ? u + 1u : u - 1u;
-    }
-    return u;
-}
-__global__ __launch_bounds__ ( 256 ) void tb_half_planes_kernel ( const DevNode* nodes, uint32_t n, float scale, DevFastNode* out_nodes ) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if ( i >= n ) return;
-    const DevNode nd = nodes[i];
-    DevFastNode out;
-    #pragma unroll
-    for ( int k = 0; k < 2; ++k ) {
-        #pragma unroll
-        for ( int a = 0; a < 3; ++a ) {
-            const float mn = ( k ? nd.min1 : nd.min0 ) [a], mx = ( k ? nd.max1 : nd.max0 ) [a];
-            const bool empty = nd.child[k] == DEV_CHILD_EMPTY || !( mn <= mx );
-            const uint32_t lo = empty ? 0x7bffu : half_outward<true> ( ( double ) mn * ( double ) scale );      // an empty slot: min = +65504, max = -65504 -- no ray enters it
-            const uint32_t hi = empty ? 0xfbffu : half_outward<false> ( ( double ) mx * ( double ) scale );
-            out.p[k][a] = lo | ( hi << 16 );
-        }
-        out.child[k] = nd.child[k];
-    }
-    out_nodes[i] = out;
-}
-hipError_t terra_fast_nodes_half_planes ( const DevNode* nodes, uint32_t n, float scale, DevFastNode* out_nodes, hipStream_t stream ) {
-    if ( n == 0 ) return hipSuccess;
-    hipLaunchKernelGGL ( tb_half_planes_kernel, dim3 ( ( n + 255 ) / 256 ), dim3 ( 256 ), 0, stream, nodes, n, scale, out_nodes );
-    hipError_t e = hipGetLastError();
-    return e != hipSuccess ? e : hipStreamSynchronize ( stream );
-}

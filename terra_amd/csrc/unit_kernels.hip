@@ -79,6 +79,7 @@ hipError_t terra_unit_moller_trumbore ( int n, const float* o, const float* d, c
 __device__ __forceinline__ Tracer unit_tracer ( const DevScene& sc, int* lds ) {
     Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.l_mats = sc.mats; T.l_lights = sc.lights; T.l_area = sc.tri_area; T.lds_nodes = 0; T.lds_tris = 0;
     T.stack = lds + threadIdx.x; T.leaves = lds + ( sc.max_stack < 1 ? 1 : sc.max_stack ) * 256 + threadIdx.x; T.leaf_cap = TERRA_LEAF_CAP_MAX;
+    T.stack_lim = 0; T.spill = nullptr; T.spill_cap = 0;
     T.stack_cap = sc.max_stack < 1 ? 1 : sc.max_stack; T.faults = nullptr; T.cull = false; T.fused = false;      // unit level: the reference's traversal decision by decision       // (unit kernels are not built with TERRA_CHECK_BOUNDS)
     return T;
 }
@@ -104,7 +105,8 @@ hipError_t terra_unit_bvh_traverse ( const DevScene& sc, int n, const float* o, 
 }
 
 // the fast tree's traversal (MODE 2) ray by ray, with the nodes each ray visited: same answers as k_bvh_traverse on any ray, axis-parallel ones included
-__global__ __launch_bounds__ ( 256 ) void k_bvh_traverse_fast ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point, uint32_t* nodes_visited ) {
+#define UNIT_FAST_STACK_LDS 32      // entries of the unit kernel's stack in LDS (32 KB per block); a deeper tree spills to `spill` like the render kernels' stacks do
+__global__ __launch_bounds__ ( 256 ) void k_bvh_traverse_fast ( DevScene sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point, uint32_t* nodes_visited, uint32_t* spill, uint32_t spill_cap, uint32_t lds_entries ) {
     extern __shared__ int lds_stack[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if ( i >= n ) return;
@@ -112,7 +114,8 @@ __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse_fast ( DevScene sc, int
     RayState s = ray_state_init ( r );
     Counters c = counters_zero();
     Tracer T; T.sc = sc; T.l_nodes = nullptr; T.l_tris = nullptr; T.l_props = nullptr; T.l_mats = sc.mats; T.l_lights = sc.lights; T.l_area = sc.tri_area; T.lds_nodes = 0; T.lds_tris = 0;
-    T.stack = lds_stack + threadIdx.x; T.leaves = T.stack; T.leaf_cap = 0; T.stack_cap = sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack; T.faults = nullptr; T.cull = false; T.fused = false;
+    T.stack = lds_stack + threadIdx.x; T.leaves = T.stack; T.leaf_cap = 0; T.stack_cap = ( int ) lds_entries; T.faults = nullptr; T.cull = false; T.fused = false;
+    T.stack_lim = ( uint32_t ) ( uintptr_t ) lds_stack + lds_entries * 1024u; T.spill = spill ? spill + ( size_t ) i * spill_cap : nullptr; T.spill_cap = spill_cap;
     ClosestRanked b = bvh_traverse_fast<1> ( T, r, s, c );
     bool f = b.tri != 0xffffffffu;
     found[i] = f ? 1 : 0;
@@ -122,8 +125,13 @@ __global__ __launch_bounds__ ( 256 ) void k_bvh_traverse_fast ( DevScene sc, int
     nodes_visited[i] = c.nodes;
 }
 hipError_t terra_unit_bvh_traverse_fast ( const DevScene& sc, int n, const float* o, const float* d, int* found, uint32_t* prim, float* point, uint32_t* nodes_visited ) {
-    hipLaunchKernelGGL ( k_bvh_traverse_fast, UNIT_GRID ( n ), ( size_t ) ( sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack ) * 256 * sizeof ( int ), 0, sc, n, o, d, found, prim, point, nodes_visited );
-    return hipGetLastError();
+    const uint32_t need = ( uint32_t ) ( sc.fast_max_stack < 1 ? 1 : sc.fast_max_stack ), lds_entries = need < UNIT_FAST_STACK_LDS ? need : UNIT_FAST_STACK_LDS, spill_cap = need - lds_entries;
+    uint32_t* spill = nullptr;
+    if ( spill_cap ) { const hipError_t e = hipMalloc ( ( void** ) &spill, ( size_t ) ( ( n + 255 ) / 256 ) * 256 * spill_cap * sizeof ( uint32_t ) ); if ( e != hipSuccess ) return e; }
+    hipLaunchKernelGGL ( k_bvh_traverse_fast, UNIT_GRID ( n ), ( size_t ) lds_entries * 256 * sizeof ( int ), 0, sc, n, o, d, found, prim, point, nodes_visited, spill, spill_cap, lds_entries );
+    hipError_t e = hipGetLastError();
+    if ( spill ) { const hipError_t e2 = hipDeviceSynchronize(); if ( e == hipSuccess ) e = e2; ( void ) hipFree ( spill ); }
+    return e;
 }
 
 __device__ void surface_to_floats ( const DevScene& sc, const Surface& sf, uint32_t object, float* q ) {

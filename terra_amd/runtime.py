@@ -66,6 +66,7 @@ _EXTRA = {
     "terra_amd_set_frame_seed": (None, [C.c_void_p, C.c_uint64]),
     "terra_amd_debug_shrink_reference_boxes": (C.c_int, [C.c_void_p, C.c_float]),
     "terra_amd_debug_pad_stack": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_debug_fast_stack_lds": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_scene_supported": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "terra_amd_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "terra_amd_get_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),

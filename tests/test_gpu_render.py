@@ -751,9 +751,10 @@ def test_decoupled_loop_matches_the_oracle(H, L, orc_lib, devmath_mode, name, in
 # only produces such stacks on inputs of pathological size, so the launches are driven through the test hook terra_amd_debug_pad_stack on an ordinary scene.
 # ---------------------------------------------------------------------------
 
-def _padded_render(L, d, mode, pad):
+def _padded_render(L, d, mode, pad, fast_lds=0):
     scene = scenes.build_scene(L, d, tree_mode=mode)
     runtime.check(L.debug_pad_stack(scene, pad))
+    runtime.check(L.debug_fast_stack_lds(scene, fast_lds))
     fb = runtime.DeviceFramebuffer(d.width, d.height)
     L.clear_error()
     rc = L.render_device(C.byref(scenes.camera_of(d)), scene, fb.pixels.data_ptr(), fb.results.data_ptr(), d.width, d.height, 0, 0, d.width, d.height, None, None)
@@ -774,6 +775,11 @@ def test_a_stack_deeper_than_64_kb_of_lds_renders(H, L, orc_lib, devmath_mode, i
             got = _padded_render(L, d, mode, pad)
             assert got["rc"] == 0 and got["err"] == "", (mode, pad, got["err"])
             assert same(H, got["pixels"], want["pixels"]) and same(H, got["acc"], want["acc"]), (mode, pad)
+    # the fast tree's stack keeps its first entries in LDS and the rest in HBM: with 1, 2 or 3 entries in LDS nearly every push of this scene goes to HBM
+    for fast_lds in (1, 2, 3):
+        got = _padded_render(L, d, 1, 0, fast_lds=fast_lds)
+        assert got["rc"] == 0 and got["err"] == "", (fast_lds, got["err"])
+        assert same(H, got["pixels"], want["pixels"]) and same(H, got["acc"], want["acc"]), fast_lds
     got = _padded_render(L, d, 0, 400)         # beyond what a block can hold: refused with a message, nothing launched, nothing rendered
     assert got["rc"] < 0 and "LDS per block" in got["err"] and not got["acc"].any()
 

@@ -154,6 +154,12 @@ def test_tool_against_the_product(H, amd_lib, orc_lib, devmath_mode, tmp_path):
     assert np.array_equal(read_pfm(out).view(np.uint32), want.view(np.uint32))
     r = subprocess.run(args + ["--fast-tree"], capture_output=True, text=True)
     assert r.returncode == 0 and np.array_equal(read_pfm(out).view(np.uint32), want.view(np.uint32))
+    # --gpus N: the in-process multi-device path (scene replicas, tiles dealt to the devices, one RCCL gather issued from C); one device here, the same calls
+    r = subprocess.run(args + ["--gpus", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert np.array_equal(read_pfm(out).view(np.uint32), want.view(np.uint32))
+    r = subprocess.run(args + ["--gpus", "64"], capture_output=True, text=True)
+    assert r.returncode == 69 and "visible" in r.stderr
 
 
 # ---------------------------------------------------------------------------

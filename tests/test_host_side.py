@@ -242,3 +242,28 @@ def test_first_error_is_process_wide_and_sticky(H, L):
     assert "sample split" in runtime.last_error() and "tree mode 7" in runtime.first_error()[1]
     L.clear_first_error(); L.clear_error()
     assert runtime.first_error() == (0, "")
+
+
+def test_binary16_planes_are_rounded_outward(H, L):
+    """the fast tree's node planes (tree_build.cpp fastbvh::half_outward): the result is the TIGHTEST binary16 on the wanted side of x -- checked against numpy's float16 for
+    normal, subnormal, tiny, huge and special values; a box made of such planes contains the box it was made from"""
+    f = L.fn("terra_amd_unit_half_outward", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p])
+    r = H.rng(5)
+    x = np.concatenate([r.uniform(-14, 14, 20000), r.uniform(-1, 1, 5000) * 10.0 ** r.uniform(-12, 5, 5000), np.float64(np.arange(-2100, 2100).astype(np.float16)) * 1.0,
+                        [0.0, -0.0, 65504.0, 65504.1, 65519.9, 65520.0, 1e6, -65504.0, -65504.1, -1e6, 5.96e-8, 2.9e-8, 1e-30, -1e-30, 6.1e-5, -6.1e-5, np.inf, -np.inf, 1e-320]]).astype(np.float64)
+    for up in (0, 1):
+        out = np.zeros(len(x), np.uint16)
+        assert f(x.ctypes.data, len(x), up, out.ctypes.data) == 0
+        h = out.view(np.float16).astype(np.float64)
+        with np.errstate(over="ignore"):
+            if up:
+                assert (h >= x).all()
+                tighter = np.nextafter(out.view(np.float16), np.float16(-np.inf)).astype(np.float64)      # the next binary16 below must already be on the wrong side
+                ok = (tighter < x) | (h == x)
+            else:
+                assert (h <= x).all()
+                tighter = np.nextafter(out.view(np.float16), np.float16(np.inf)).astype(np.float64)
+                ok = (tighter > x) | (h == x)
+        assert ok.all(), (x[~ok][:5], h[~ok][:5])
+    nan = np.array([np.nan]); o = np.zeros(1, np.uint16)
+    assert f(nan.ctypes.data, 1, 1, o.ctypes.data) == 0 and o[0] == 0x7c00 and f(nan.ctypes.data, 1, 0, o.ctypes.data) == 0 and o[0] == 0xfc00      # the widest value either way
