@@ -44,6 +44,7 @@ const char* terra_amd_last_error ( void ) __attribute__ ( ( weak ) );
 int         terra_amd_set_tree_mode ( HTerraScene, int ) __attribute__ ( ( weak ) );
 int         terra_amd_set_sample_split ( HTerraScene, int ) __attribute__ ( ( weak ) );
 void        terra_amd_set_frame_seed ( HTerraScene, uint64_t ) __attribute__ ( ( weak ) );
+int         terra_amd_init ( void ) __attribute__ ( ( weak ) );
 int         terra_amd_set_devices ( const int*, int ) __attribute__ ( ( weak ) );
 int         terra_amd_device_count ( void ) __attribute__ ( ( weak ) );
 int         terra_amd_render_multi ( const TerraCamera*, HTerraScene, const TerraFramebuffer*, size_t, size_t, size_t, size_t, size_t ) __attribute__ ( ( weak ) );
@@ -445,6 +446,7 @@ static const char* kHelp =
 int main ( int argc, char** argv ) {
     for ( int i = 1; i < argc; ++i ) if ( !strcmp ( argv[i], "--help" ) || !strcmp ( argv[i], "-h" ) ) { fputs ( kHelp, stdout ); return 0; }
     if ( argc < 3 ) { fprintf ( stderr, "usage: terra_headless scene.obj out.{png,ppm,pfm,hdr} [options]\n" ); return 64; }
+    if ( terra_amd_init ) ( void ) terra_amd_init();      /* before anything touches the GPU (libterra_amd.so only) */
     size_t W = 800, H = 600, spp = 8, bounces = 4, tile = 0;     /* defaults of satellite/include/Config.hpp:19-113 */
     int integrator = kTerraIntegratorDirect, tonemap = kTerraTonemappingOperatorLinear, flip = 1, fast = -1, have_seed = 0, split = -1, apollo = 1, gpus = 0;
     const char* dump_path = NULL; int no_render = 0;

@@ -56,6 +56,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime st
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (MI355X_MICROARCH.md "Execution model")
+TA_PEAK_GCYC = 256 * 2.4              # one texture addresser per CU, 2.4 GHz: G addresser-cycles per second
+L2_GATHER_GBS = 16800.0               # MI355X_MICROARCH.md "Indexed rows": rows gathered from the XCDs' L2, 16.8-18.8 TB/s chip-wide (the lower figure)
 TILE = 64
 # Sample split of the timed launches (terra_amd_set_sample_split): the frame equals that of this many successive calls of spp/split samples. With the job queue a
 # launch wants many jobs per resident lane -- at N = 8 a rank renders an eighth of the frame -- and short jobs at its end (Cornell 512 spp: split 8 / 16 / 32 / 64
@@ -307,6 +309,28 @@ def pmc_file():
     return fs[-1] if fs else None
 
 
+# cycles one wave64 VALU instruction occupies a SIMD's issue, by class, at 2.4 GHz: measured per instruction with 4 waves per SIMD on every CU
+# (tools/ubench/valu_rates.hip, profiles/r02_measurements/valu_rates.log). The dynamic class counts come from the SQ_INSTS_VALU_* counters (tools/profile_round.py passes
+# mix1 / mix2); what they do not name ("other": compares, selects, min / max, permutes, moves, shifts) is priced with the static mix of exactly those opcodes in the
+# kernel's code object (rec["other_cycles"], written by tools/profile_round.py), 4.1 when that is absent.
+VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.55, "SQ_INSTS_VALU_MUL_F32": 2.49, "SQ_INSTS_VALU_FMA_F32": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.1, "SQ_INSTS_VALU_ADD_F64": 4.31,
+                     "SQ_INSTS_VALU_MUL_F64": 4.14, "SQ_INSTS_VALU_FMA_F64": 4.14, "SQ_INSTS_VALU_TRANS_F64": 16.2, "SQ_INSTS_VALU_CVT": 4.2, "SQ_INSTS_VALU_INT32": 3.6, "SQ_INSTS_VALU_INT64": 4.4,
+                     "SQ_INSTS_VALU_ADD_F16": 4.2, "SQ_INSTS_VALU_MUL_F16": 4.2, "SQ_INSTS_VALU_FMA_F16": 4.2, "SQ_INSTS_VALU_TRANS_F16": 8.1}
+
+
+def valu_mix_ceiling(rec):
+    """fraction of the nominal VALU issue peak (2 cycles per wave64 instruction) that this kernel's DYNAMIC instruction mix can reach at most: total / sum(class count x class cycles) x 2"""
+    pmc = rec.get("pmc", {})
+    total = pmc.get("SQ_INSTS_VALU") or rec.get("SQ_INSTS_VALU")
+    named = {k: pmc[k] for k in VALU_CLASS_CYCLES if k in pmc}
+    if not total or len(named) < 6:
+        return None
+    other = max(0.0, total - sum(named.values()))
+    cycles = sum(v * VALU_CLASS_CYCLES[k] for k, v in named.items()) + other * float(rec.get("other_cycles", 4.1))
+    return {"frac_of_peak": round(2.0 * total / cycles, 4), "mean_cycles_per_instr": round(cycles / total, 3), "other_share": round(other / total, 4),
+            "classes": {k.replace("SQ_INSTS_VALU_", ""): round(v / total, 4) for k, v in named.items() if v}}
+
+
 def roofline(key, st, kernel_ms, lds_resident, world, pmc=None):
     """st: device work counters per launch; the PMC record (per launch of the render kernel) comes from the newest profiles/rNN_pmc.json"""
     alg = algorithmic_bytes(st)
@@ -321,30 +345,59 @@ def roofline(key, st, kernel_ms, lds_resident, world, pmc=None):
     if rec:
         out["pmc_stale"] = rec.get("source_digest") != source_digest()
         out["pmc_kernel_ms"] = rec.get("kernel_ms")
+    c = rec.get("pmc", {})
     traffic = rec.get("hbm_bytes_per_launch")
-    insts = rec.get("SQ_INSTS_VALU")
+    insts = rec.get("SQ_INSTS_VALU") or c.get("SQ_INSTS_VALU")
     valu = insts / t / 1e9 if insts else None                      # G wave64 VALU instructions per second, whole chip
     fabric = traffic / t / 1e9 if traffic else None                # GB/s the L2 moved on its fabric side
     valu_frac = round(valu / VALU_PEAK_GINST, 4) if valu else None
     fabric_frac = round(fabric / HBM_PEAK_GBS, 4) if fabric else None
+    mix = valu_mix_ceiling(rec) if rec else None
     out.update({"traffic": traffic, "valu_insts_per_launch": insts, "lane_util": rec.get("lane_util"), "lds_bank_conflict_frac": rec.get("lds_bank_conflict_frac"),
                 "valu_frac": valu_frac, "l2_fabric_frac": fabric_frac})
-    # the bound reported is the resource the kernel comes closest to saturating
-    if valu_frac is not None and (fabric_frac is None or valu_frac >= fabric_frac):
-        out.update({"bound": "valu", "achieved": round(valu, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": valu_frac})
-    elif fabric_frac is not None:
-        out.update({"bound": "l2_fabric", "achieved": round(fabric, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fabric_frac})
+    if mix:
+        out["valu_mix_ceiling"] = mix                               # what this instruction mix can issue at most, as a fraction of the nominal peak
+        if valu_frac:
+            out["valu_frac_of_mix_ceiling"] = round(valu_frac / mix["frac_of_peak"], 4)
+    # scenes read from global memory: the texture addresser (every wave-level load instruction costs it ~21-27 cycles whatever its width), the L1 <- L2 gather and how long
+    # the waves sit in s_waitcnt -- from the gather passes of tools/profile_round.py (TA / TCP / TCC / SQ_WAIT counters, each pass its own run)
+    ta_frac = gather_frac = None
+    if c.get("TA_TA_BUSY_sum"):
+        ta = c["TA_TA_BUSY_sum"] / t / 1e9                           # G TA-busy cycles per second, summed over the 256 addressers
+        ta_frac = round(ta / TA_PEAK_GCYC, 4)
+        out.update({"ta_busy_frac": ta_frac, "vmem_wave_instr_per_launch": c.get("TA_FLAT_READ_WAVEFRONTS_sum"),
+                    "ta_cycles_per_load_instr": round(c["TA_TA_BUSY_sum"] / c["TA_FLAT_READ_WAVEFRONTS_sum"], 2) if c.get("TA_FLAT_READ_WAVEFRONTS_sum") else None})
+    if c.get("TCP_TCC_READ_REQ_sum"):
+        gbs = c["TCP_TCC_READ_REQ_sum"] * 128.0 / t / 1e9            # a request = one 128-byte line
+        gather_frac = round(gbs / L2_GATHER_GBS, 4)
+        out["l2_gather"] = {"achieved_gbs": round(gbs, 1), "roof_gbs": L2_GATHER_GBS, "frac": gather_frac, "requests_per_launch": c["TCP_TCC_READ_REQ_sum"],
+                            "l1_hit": round(1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 4) if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+                            "l2_hit": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4) if c.get("TCC_HIT_sum") else None}
+    if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES"):
+        out["wave_wait_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)       # share of the resident waves' cycles spent parked in s_waitcnt
+    # the bound reported is the resource the kernel comes closest to saturating; VALU issue is compared through its mix ceiling when that is known
+    cands = []
+    if valu_frac is not None:
+        cands.append(("valu", (valu_frac / mix["frac_of_peak"]) if mix else valu_frac, valu, VALU_PEAK_GINST, "G wave-instr/s", valu_frac))
+    if ta_frac is not None:
+        cands.append(("ta", ta_frac, c["TA_TA_BUSY_sum"] / t / 1e9, TA_PEAK_GCYC, "G addresser-cycles/s", ta_frac))
+    if gather_frac is not None:
+        cands.append(("l2_gather", gather_frac, c["TCP_TCC_READ_REQ_sum"] * 128.0 / t / 1e9, L2_GATHER_GBS, "GB/s", gather_frac))
+    if fabric_frac is not None:
+        cands.append(("l2_fabric", fabric_frac, fabric, HBM_PEAK_GBS, "GB/s", fabric_frac))
+    if cands:
+        b = max(cands, key=lambda x: x[1])
+        out.update({"bound": b[0], "achieved": round(b[2], 1), "peak": b[3], "unit": b[4], "frac": round(b[5], 4)})
     else:
-        out.update({"bound": "valu" if lds_resident else "l2_fabric", "achieved": None, "peak": VALU_PEAK_GINST if lds_resident else HBM_PEAK_GBS,
-                    "unit": "G wave-instr/s" if lds_resident else "GB/s", "frac": None})
+        out.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": None})
     if lds_resident:
         out["note"] = ("scene staged in LDS: the kernel is bound by VALU issue. achieved = SQ_INSTS_VALU (profiles/rNN_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
-                       "A stream of nothing but v_add_f32 sustains 0.96 G/s per SIMD on this part and min/max/cmp/cndmask/f64/integer-multiply streams 0.57 (profiles/r02_measurements/valu_rates.log), so frac ~0.7 is "
-                       "saturation for this instruction mix; lane_util says how many of the issued lanes did work; `traffic` is what HBM moved (framebuffer only)")
+                       "valu_mix_ceiling = what the kernel's dynamic instruction mix (SQ_INSTS_VALU_* counters x the measured per-class issue cycles, profiles/r02_measurements/valu_rates.log) can reach of that peak; "
+                       "lane_util says how many of the issued lanes did work; `traffic` is what the L2 moved on its fabric side")
     else:
-        out["note"] = ("scene read from global memory (L2 / Infinity Cache resident): the kernel is latency bound -- a ray's node fetches are a dependent chain -- and saturates neither resource; valu_frac = SQ_INSTS_VALU / "
-                       "kernel time against the 1,229 G/s issue peak, l2_fabric_frac = bytes the L2 moved on its fabric side (FETCH_SIZE x 2 + WRITE_SIZE PMC passes, Infinity Cache hits included) / kernel time against the "
-                       "8 TB/s HBM peak; `bound` names the larger of the two")
+        out["note"] = ("scene read from global memory (L2 / Infinity Cache resident). Three resources are close to their limits together and `bound` names the closest: VALU issue against the ceiling of "
+                       "the kernel's instruction mix (valu_frac_of_mix_ceiling), the texture addresser (ta_busy_frac: it spends ~21-27 cycles per wave-level load instruction whatever the width, so "
+                       "loads per ray is what counts, not bytes), and the L1 <- L2 line gather against the guide's 16.8 TB/s L2-hit figure (l2_gather); wave_wait_frac = share of wave cycles in s_waitcnt")
     return out
 
 
@@ -607,6 +660,24 @@ def host_api(c, d, tree, split, steps):
     return out
 
 
+def multi_device_block(workload_name, limit_s=300.0):
+    """The in-process multi-GPU path of the C-ABI (terra_amd_set_devices + terra_amd_render_multi: tiles dealt to the devices from ONE process, one RCCL gather issued by
+    the library) on 1, 2, 4, ... of the devices THIS process sees -- run as a child (tools/multi_device_bench.py) with a time limit, so that a failure or a hang of a device
+    count that has never run before cannot take the bench line with it. On a one-GPU box this is the one-device self-test of that path."""
+    cmd = [sys.executable, str(ROOT / "tools" / "multi_device_bench.py"), "--workload", workload_name, "--steps", "2"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"tools/multi_device_bench.py did not finish within {limit_s:.0f} s"}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": f"tools/multi_device_bench.py exited with code {r.returncode}: " + (r.stderr or "")[-400:]}
+    blk = json.loads(line[-1])
+    blk["note"] = ("terra_amd_render_multi() on a pinned host framebuffer, PCIe included, from one process; more than one device has only ever run where this line says so "
+                   "(`runs` lists the device counts that ran here)")
+    return blk
+
+
 EXTRA_WORKLOADS = [
     # (workload, tree, integrator, split, steps, warmup, prewarm rectangle, CPU seconds)
     # (sample split: with the job queue a launch wants >= ~20 jobs per resident lane, or its last jobs ramp down alone: hall 256 spp split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms)
@@ -657,6 +728,7 @@ def main():
             # SURVEY.md 8(d)'s own definition of the metric -- wall time of terra_render(), kernel + the tile's D2H included -- as a top-level key beside `value`
             # (which is the device-resident rate the bench contract asks for)
             out["value_terra_render"] = out["host_api"]["full_frame_call"]["value"]
+            out["host_api"]["multi_device"] = multi_device_block(args.workload)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
         headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == DEFAULT_SPLIT

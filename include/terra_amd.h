@@ -44,6 +44,19 @@ void        terra_amd_clear_first_error ( void );
    tile it has rendered (not of the frame). Released, with the thread's stream, when the thread exits. */
 size_t      terra_amd_thread_staging_bytes ( void );
 
+/* Process set-up a client may ask for, first thing in main() (before anything touches the GPU): ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware
+   queues -- 4 by default -- and kernels of streams that share a queue run one after the other; a client that calls terra_render() from 8 worker threads, as
+   the reference's does (satellite/src/Renderer.cpp:70-98), wants 8. terra_amd_init() sets that variable unless the user already has; it has no effect once the
+   HIP runtime is up. Optional: a client that does not call it gets ROCm's default. (The library never changes the environment on its own.) */
+int  terra_amd_init ( void );
+/* Process-wide switches of the commit path (all optional):
+   terra_amd_set_commit_timing(1)  prints the phases of terra_scene_commit() on stderr;
+   terra_amd_set_build_threads(n)  host threads of the fast tree's builder (0 = as many as the process may use, at most 16; the tree does not depend on it);
+   terra_amd_set_azimuth_table(0)  scenes committed from now on compute the samplers' sin / cos instead of reading the 128 MB per-device table (same bits). */
+void terra_amd_set_commit_timing ( int on );
+int  terra_amd_set_build_threads ( int threads );
+void terra_amd_set_azimuth_table ( int on );
+
 /* Device selection for subsequent commits/renders issued by this thread's
    scenes: one device (one process per GPU is bench.py's layout, DESIGN.md "Multi-GPU"), or a set of devices driven from this process (below). */
 int  terra_amd_device_count ( void );

@@ -166,6 +166,9 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_WAVES_LIGHT
 #define TERRA_WAVES_LIGHT 4
 #endif
+#ifndef TERRA_WAVES_MIS          // Direct + MIS on LDS-resident diffuse scenes, split at its two rays (TERRA_COUPLED_MIS_SPLIT): 5 -> 158.1 ms with 116 B of scratch, 4 -> 165.4 with none
+#define TERRA_WAVES_MIS 5        // (Cornell 512 spp; profiles/r04_measurements/ab_light_split.log; unsplit, round 3: 5 -> 191.9, 4 -> 178.9)
+#endif
 #ifndef TERRA_WAVES_DIRECT_PHONG // ... also the diffuse + Phong variant (A/B)
 #define TERRA_WAVES_DIRECT_PHONG 0
 #endif
@@ -225,7 +228,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #endif
 #define TERRA_IS_LIGHT(I) ( ( I ) == 1 || ( I ) == 2 || ( I ) == 6 )
 #define TERRA_WAVES_FOR(I, K, M) ( ( M ) >= 2 ? ( ( K ) == 1 ? ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_LIGHT : TERRA_WAVES_FAST_TREE ) : ( TERRA_IS_LIGHT ( I ) ? TERRA_WAVES_FAST_TREE_GENERIC_LIGHT : TERRA_WAVES_FAST_TREE_GENERIC ) ) \
-                                 : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : ( ( I ) == 1 && ( ( K ) == 1 || ( TERRA_WAVES_DIRECT_PHONG && ( K ) == 3 ) ) ) ? TERRA_WAVES_DIRECT : TERRA_WAVES_LIGHT ) \
+                                 : TERRA_IS_LIGHT ( I ) ? ( ( M ) == 0 ? TERRA_WAVES_GLOBAL_LIGHT : ( ( I ) == 1 && ( ( K ) == 1 || ( TERRA_WAVES_DIRECT_PHONG && ( K ) == 3 ) ) ) ? TERRA_WAVES_DIRECT : ( ( I ) == 2 && ( K ) == 1 ) ? TERRA_WAVES_MIS : TERRA_WAVES_LIGHT ) \
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
@@ -347,18 +350,22 @@ TD bool job_pixel ( const DevRenderParams& p, uint32_t job, uint32_t& px, uint32
 }
 // aux: the lane's parked words (TERRA_AUX_WORDS rows of 256): [0], [256], [512] the job's radiance sum; [768] the job; [1024] the lane's draw count at the job's
 // start; row 5 holds, per wave, the pool {next job, end} at [1280 + 64 * wave + 0 / 1] relative to thread 0's column
-// (volatile: the pool is how the lanes of a wave tell each other which jobs are taken -- lane 0 of one group of callers writes it, another group reads it on a later call;
-//  a plain access would let the compiler keep a stale copy in a register across the render loop's back edge)
-TD volatile uint32_t* job_pool_of_wave ( float* aux_of_thread ) { return reinterpret_cast<volatile uint32_t*> ( aux_of_thread - threadIdx.x ) + 1280 + ( threadIdx.x & ~63u ); }
+// (the pool is how the lanes of a wave tell each other which jobs are taken -- lane 0 of one group of callers writes it, another group reads it on a later call -- so its
+//  words are read and written with relaxed wave-scope atomics: plain ds_read / ds_write instructions that the compiler may neither keep in a register across the render
+//  loop's back edge nor merge. `volatile` says the same and costs the Simple kernel 12 bytes of scratch, the Direct one 20 more.)
+typedef uint32_t PoolWord;
+TD uint32_t pool_load ( const PoolWord* w ) { return __hip_atomic_load ( w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT ); }
+TD void pool_store ( PoolWord* w, uint32_t v ) { __hip_atomic_store ( w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT ); }
+TD PoolWord* job_pool_of_wave ( float* aux_of_thread ) { return reinterpret_cast<PoolWord*> ( aux_of_thread - threadIdx.x ) + 1280 + ( threadIdx.x & ~63u ); }
 TD void job_init_lane ( const DevRenderParams& p, float* aux ) {
     reinterpret_cast<uint32_t*> ( aux ) [768] = TERRA_JOB_NONE;
     if ( ( threadIdx.x & 63u ) == 0 ) {       // the wave's first pool
-        volatile uint32_t* pool = job_pool_of_wave ( aux );
-        if ( p.job_queue ) { pool[0] = 0; pool[1] = 0; }      // empty: the first ask claims a batch from the queue like every later one. (No job is RESERVED for a block by its index:
+        PoolWord* pool = job_pool_of_wave ( aux );
+        if ( p.job_queue ) { pool_store ( pool, 0 ); pool_store ( pool + 1, 0 ); }      // empty: the first ask claims a batch from the queue like every later one. (No job is RESERVED for a block by its index:
                                                               // a block that the GPU only makes resident late -- when others have drained the queue -- finds nothing and leaves.)
         else {                                                // plain launch (no queue): the 64 jobs of the wave's own index
             const uint32_t total = p.job_blocks * 256u, first = blockIdx.x * 256u + threadIdx.x;
-            pool[0] = first < total ? first : total; pool[1] = first + TERRA_JOB_BATCH < total ? first + TERRA_JOB_BATCH : total;
+            pool_store ( pool, first < total ? first : total ); pool_store ( pool + 1, first + TERRA_JOB_BATCH < total ? first + TERRA_JOB_BATCH : total );
         }
     }
 }
@@ -376,11 +383,11 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
         p.partials[ ( ( size_t ) chunk * ( p.job_blocks >> p.split_log2 ) + blk ) * 256 + ( fin & 255u )] = make_float4 ( aux[0], aux[256], aux[512], __uint_as_float ( COUNT == 2 ? c.rand_calls - auxu[1024] : 0u ) );
         auxu[768] = TERRA_JOB_NONE;
     }
-    volatile uint32_t* pool = job_pool_of_wave ( aux );
+    PoolWord* pool = job_pool_of_wave ( aux );
     const unsigned long long m = __ballot ( 1 );                 // the lanes here
     const uint32_t lane = threadIdx.x & 63u, n = ( uint32_t ) __popcll ( m ), ahead = ( uint32_t ) __popcll ( m & ( ( 1ull << lane ) - 1ull ) );
     const uint32_t total = p.job_blocks * 256u;
-    uint32_t next = pool[0], end = pool[1];
+    uint32_t next = pool_load ( pool ), end = pool_load ( pool + 1 );
     const uint32_t take = n < end - next ? n : end - next;
     uint32_t job = next + ahead;
     bool got = ahead < take;
@@ -396,11 +403,11 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
         if ( !got ) { job = next + ( ahead - take ); got = ahead - take < take2; }
         next += take2;
     }
-    if ( ahead == 0 ) { pool[0] = next; pool[1] = end; }
+    if ( ahead == 0 ) { pool_store ( pool, next ); pool_store ( pool + 1, end ); }
     if ( !got ) { j.exhausted = true; return; }                  // the queue is monotone: a batch that does not cover the askers means nothing is left, ever
     uint32_t chunk;
     int prior_samples;
-    if ( TERRA_JOB_STREAM_TABLE && TABLE && p.job_streams ) {      // (no table: a launch whose table would not fit the scratch bound keys its streams here, like the kernels that wait on memory)
+    if constexpr ( TERRA_JOB_STREAM_TABLE && TABLE ) {
         const uint4 e1 = p.job_streams[2 * ( size_t ) job + 1];       // keyed by terra_job_streams_kernel (below): the job's pixel comes with it, the decode's divisions are not repeated here
         if ( e1.z == 0xffffffffu ) return;                                 // (a pixel outside the rectangle)
         const uint4 e0 = p.job_streams[2 * ( size_t ) job];
@@ -478,7 +485,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
                         V3 wo = neg ( ray.d );
                         Ray ray_a;
-                        pend = mis_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
+                        pend = mis_prepare<COUNT, KINDS, MODE> ( T, sf, point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
                         b_o = point + sf.normal * 0.0001f;        // surface_ray ( sf, point, bsdf_dir, 1.f ) without the divisions
                         cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d, sp );
                         cont_o = point + sf.normal * 0.0001f;     // (the divisions of surface_ray are redone when the ray starts)
@@ -531,7 +538,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         V3 point = shade_surface<COUNT, MODE, KINDS> ( T, ray, lt.best, sf, c );
                         V3 wo = neg ( ray.d );
                         Ray shadow_ray;
-                        pend = direct_prepare<COUNT, KINDS> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
+                        pend = direct_prepare<COUNT, KINDS, MODE> ( T, sf, point, wo, throughput, bounce, rs.b, c, shadow_ray );
                         cont = path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, cont_d, sp );
                         cont_o = point + sf.normal * 0.0001f;     // surface_ray ( sf, point, wi, 1.f ) without the divisions: they are taken when the ray starts
                         ro = shadow_ray.o; rd = shadow_ray.d; shadow = true; start = true;
@@ -613,9 +620,18 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
         else Lo = Lo + t;
     };
     auto lo_deposit = [&] () { if ( LO_LDS ) deposit ( acc_lds, v3 ( lo_lds[0], lo_lds[256], lo_lds[512] ) ); else deposit ( acc_lds, Lo ); };
+#ifndef TERRA_COUPLED_DIRECT_SPLIT     // the coupled loop's Direct integrator split at its shadow ray (below); 0: integrate_direct as one piece (A/B)
+#define TERRA_COUPLED_DIRECT_SPLIT 1
+#endif
+#ifndef TERRA_COUPLED_MIS_SPLIT        // ... and Direct + MIS at its two rays
+#define TERRA_COUPLED_MIS_SPLIT 1
+#endif
+#ifndef TERRA_REGEN_MIN           // (A/B) lanes whose path ended wait until this many of the wave's lanes have, then start their next camera rays TOGETHER (same bounce depth afterwards)
+#define TERRA_REGEN_MIN 1
+#endif
     while ( true ) {
         const bool any_alive = __any ( alive );
-        if ( !alive ) {
+        if ( !alive && ( TERRA_REGEN_MIN <= 1 || !any_alive || __popcll ( __ballot ( !alive ) ) >= TERRA_REGEN_MIN ) ) {
             // (a lane waits at the boundary until TERRA_JOB_FETCH_MIN lanes do, or nobody is tracing: the switch then serves several lanes per execution)
             if ( jb.s == p.chunk_spp && ( TERRA_JOB_FETCH_MIN <= 1 || !any_alive || __popcll ( __ballot ( jb.s == p.chunk_spp ) ) >= TERRA_JOB_FETCH_MIN ) ) job_next<COUNT, MODE == 1> ( p, acc_lds, jb, rs, c );
             if ( jb.exhausted ) break;
@@ -638,11 +654,38 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
             if ( h.hit ) {
                 PS_WAVE ( c, kPsShadeIter ); PS_LANE ( c, kPsShadeLanes );
                 V3 wo = neg ( ray.d ), wi;
+                // Direct on scenes whose emissive attributes are constants: the integrator is split at its shadow ray. Everything that does not depend on the ray's outcome --
+                // the light sample, both possible values of the integrator, then the continuation's draws, in the reference's order (src/Terra.c:1068-1079 after :1349-1426) --
+                // comes BEFORE the shadow traversal, so that the traversal runs with a pending pair and a continuation ray in registers instead of the whole shaded surface
+                constexpr bool SPLIT_DIRECT = TERRA_COUPLED_DIRECT_SPLIT && INTEGRATOR == 1 && ( KINDS & ( TERRA_KIND_TEX | TERRA_KIND_SAMPLER ) ) == 0;
+                if constexpr ( SPLIT_DIRECT ) {
+                    Ray shadow_ray;
+                    const DirectPending pend = direct_prepare<COUNT, KINDS, MODE> ( T, sf, h.point, wo, throughput, bounce, rs.b, c, shadow_ray );
+                    pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );
+                    end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
+                    if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }
+                    const uint32_t tri = scene_raycast_triangle<COUNT, MODE> ( T, shadow_ray, c );
+                    lo_add ( tri == pend.expected ? pend.vis : pend.hid );
+                } else if constexpr ( TERRA_COUPLED_MIS_SPLIT && INTEGRATOR == 2 && ( KINDS & ( TERRA_KIND_TEX | TERRA_KIND_SAMPLER ) ) == 0 ) {
+                    // Direct + MIS split the same way at its two rays (mis_prepare / mis_finish_b, src/Terra.c:1428-1587): A, the ray to the light sample, only has to
+                    // name the triangle it hits; B, the BSDF-sampled ray, needs the surface it hits
+                    Ray ray_a; V3 b_d;
+                    const MisPending pend = mis_prepare<COUNT, KINDS, MODE> ( T, sf, h.point, wo, throughput, bounce, rs.b, c, ray_a, b_d );
+                    const V3 next_o = h.point + sf.normal * 0.0001f;          // surface_ray ( sf, h.point, direction, 1.f ) for B and for the continuation alike
+                    end = !path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, wi, sp );
+                    if ( !end ) { ro = next_o; rd = wi; }
+                    const uint32_t tri_a = scene_raycast_triangle<COUNT, MODE> ( T, ray_a, c );
+                    const V3 lo_a = tri_a == pend.expected ? pend.a_vis : pend.a_hid;
+                    Surface lsf;
+                    const RaycastResult hb = scene_raycast<COUNT, MODE, KINDS> ( T, make_ray ( next_o, b_d ), lsf, c );
+                    lo_add ( mis_finish_b<MODE> ( T, pend, lo_a, hb.hit, hb.object, hb.tri, hb.point, lsf, b_d ) );
+                } else {
                 lo_add ( integrate<INTEGRATOR, COUNT, MODE, KINDS> ( T, ray, sf, h.point, wo, throughput, bounce, rs.b, c ) );
                 if ( !pre_draw ) pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );
                 if constexpr ( ( KINDS & TERRA_KIND_SAMPLER ) != 0 ) path_apply_sampler ( pd, sp, bounce );
                 end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                 if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }      // surface_ray ( sf, h.point, wi, 1.f ): its make_ray is the one at the top of this block
+                }
             } else if ( ( KINDS & TERRA_KIND_ENV ) && T.sc.env_mode && !env_reaches_by_samples<INTEGRATOR, KINDS> ( T.sc, bounce ) ) {     // extension: the reference's commented-out "Lo += throughput" (src/Terra.c:1056)
                 throughput = had ( throughput, environment_eval ( T.sc, ray.d ) );
                 lo_add ( throughput );
@@ -881,15 +924,7 @@ hipError_t terra_launch_job_streams ( const DevRenderParams& p, hipStream_t stre
     hipLaunchKernelGGL ( terra_job_streams_kernel, dim3 ( p.job_blocks ), dim3 ( 256 ), 0, stream, p );
     return hipGetLastError();
 }
-// (p.job_blocks set). Above TERRA_JOB_STREAM_TABLE_MAX_BYTES the launch goes without the table (in-kernel keying: the same streams, 2-3 % slower on the LDS-resident kernels): a 4K frame at
-// 64 lanes per pixel would otherwise ask for 17 GB of scratch per concurrent stream for a 3 % gain
-#ifndef TERRA_JOB_STREAM_TABLE_MAX_BYTES
-#define TERRA_JOB_STREAM_TABLE_MAX_BYTES ( size_t ( 4 ) << 30 )
-#endif
-size_t terra_job_streams_bytes ( const DevRenderParams& p ) {
-    const size_t bytes = ( TERRA_JOB_STREAM_TABLE && p.lds_mode == 1 ) ? ( size_t ) p.job_blocks * 256 * 32 : 0;
-    return bytes <= TERRA_JOB_STREAM_TABLE_MAX_BYTES ? bytes : 0;
-}
+size_t terra_job_streams_bytes ( const DevRenderParams& p ) { return ( TERRA_JOB_STREAM_TABLE && p.lds_mode == 1 ) ? ( size_t ) p.job_blocks * 256 * 32 : 0; }      // (p.job_blocks set)
 hipError_t terra_launch_resolve ( const DevRenderParams& p, hipStream_t stream ) {
     uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return hipSuccess;

@@ -276,6 +276,9 @@ struct HostLight { uint32_t object; float area; TerraFloat3 power; };
 #endif
 #define TERRA_REACH_MAX_COORD 1e6f       // beyond it (c - o) x 2^100 (the fast tree's clamped slab test) approaches the binary32 range: replica
 #define TERRA_CULL_MAX_COORD 13.0f       // limit of the numeric containment check (derivation above verify_reference_leaf_boxes)
+#ifndef TERRA_SCRATCH_MAX_GB
+#define TERRA_SCRATCH_MAX_GB 64                     // most scratch one launch may take from the device's pool (launch_render)
+#endif
 #define TERRA_FAST_STACK_MAX 2048                   // stack entries per ray beyond which the fast tree is not used (its spill space: 4 B x entries x 327,680 resident lanes)
 struct Scene {
     TerraSceneOptions opts, new_opts;
@@ -322,6 +325,7 @@ struct Scene {
     bool sampler_integration = false;   // terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce (a launch parameter)
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
+    std::atomic<bool> warned_camera { false };      // the per-call fallback (camera outside camera_limit) has been reported on stderr once
     int test_pad_stack = 0;                         // terra_amd_debug_pad_stack (tests only): extra stack entries every launch plans
     int test_fast_stack_lds = 0;                    // terra_amd_debug_fast_stack_lds (tests only): entries of a fast-tree launch's stack kept in LDS (0: the default), the rest spills to HBM
     float test_shrink_reference_boxes = 0.f;       // terra_amd_debug_shrink_reference_boxes (tests only): the device copy of the reference tree's boxes is shrunk by this much
@@ -329,8 +333,19 @@ struct Scene {
 
 static Scene* S ( HTerraScene h ) { return ( Scene* ) h; }
 
-// TERRA_AMD_TIMING=1: commit phases on stderr (tools/scale_triangles.py reads them)
-static bool timing_on() { static const bool on = getenv ( "TERRA_AMD_TIMING" ) != nullptr; return on; }
+// terra_amd_set_commit_timing(1): commit phases on stderr (tools/scale_triangles.py reads them)
+static std::atomic<bool> g_commit_timing { false };
+static bool timing_on() { return g_commit_timing.load ( std::memory_order_relaxed ); }
+bool terra_commit_timing_on() { return timing_on(); }          // (tree_build.cpp prints its passes too)
+extern "C" void terra_amd_set_commit_timing ( int on ) { g_commit_timing.store ( on != 0, std::memory_order_relaxed ); }
+// host threads of the fast tree's builder (tree_build.cpp): 0 = as many as the process may use, at most 16
+static std::atomic<int> g_build_threads { 0 };
+int terra_build_threads() { return g_build_threads.load ( std::memory_order_relaxed ); }
+extern "C" int terra_amd_set_build_threads ( int threads ) {
+    if ( threads < 0 || threads > 256 ) return fail ( kTerraAmdErrBadArgument, "build threads must be 0 (automatic) .. 256" );
+    g_build_threads.store ( threads, std::memory_order_relaxed );
+    return 0;
+}
 static double now_s() { return std::chrono::duration<double> ( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 static void phase ( const char* what, double& t0 ) { if ( !timing_on() ) return; double t = now_s(); fprintf ( stderr, "[terra_amd timing] %-28s %8.2f ms\n", what, ( t - t0 ) * 1e3 ); t0 = t; }
 
@@ -619,9 +634,11 @@ static void build_reach_tables ( const std::vector<DevNode>& nodes, const std::v
 
 // DevScene::sincos24, one table per device for the life of the process (128 MB of its 288 GB; filled by tdm_sincosf_pair itself, ~1 ms). nullptr when it cannot
 // be had (or TERRA_AMD_NO_SINCOS_TABLE is set: A/B runs) -- the kernels then compute.
+static std::atomic<bool> g_azimuth_table { true };
+extern "C" void terra_amd_set_azimuth_table ( int on ) { g_azimuth_table.store ( on != 0, std::memory_order_relaxed ); }      // (takes effect at the next commit)
 static const float2* sincos_table_of ( int device ) {
     static std::mutex lock; static const float2* tables[64]; static bool tried[64];
-    if ( device < 0 || device >= 64 || getenv ( "TERRA_AMD_NO_SINCOS_TABLE" ) ) return nullptr;
+    if ( device < 0 || device >= 64 || !g_azimuth_table.load ( std::memory_order_relaxed ) ) return nullptr;
     std::lock_guard<std::mutex> g ( lock );
     if ( tried[device] ) return tables[device];
     tried[device] = true;
@@ -914,6 +931,10 @@ static int upload_scene ( Scene* s ) {
     }
     if ( s->tree_mode == 2 && auto_ok ) s->tree_note = s->use_fast ? ( s->fast_on_device ? "containment verified: fast tree built on the device (LBVH; scene is not LDS-resident)" : "containment verified: fast tree (scene is not LDS-resident)" ) : ( resident ? "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)" : s->tree_note );
     if ( s->reach && !s->fast_on_device ) build_reach_tables ( nodes, tris, soup_of_fast, reach_margin, reach_tabs );
+    // The automatic mode's fallbacks are correct and 10-20 x slower on scenes of this size (hall: 110 against 2,400 Msamples/s): say so where a client looks, once per commit.
+    if ( s->tree_mode == 2 && !s->use_fast && !resident && ntri >= 2 )
+        fprintf ( stderr, "[terra_amd] warning: this scene (%zu triangles) is traversed through the reference tree%s, typically 10-20 x slower than the fast tree -- %s\n", ntri,
+                  s->cull_ok ? " with the leaf-box cull" : " decision by decision", s->tree_note.c_str() );
     // one blob, 256-byte aligned sections
     auto align = [] ( size_t v ) { return ( v + 255 ) & ~size_t ( 255 ); };
     size_t o_nodes = 0, o_tris = align ( o_nodes + nodes.size() * sizeof ( DevNode ) ), o_props = align ( o_tris + tris.size() * sizeof ( DevTri ) );
@@ -974,7 +995,7 @@ static int upload_scene ( Scene* s ) {
         // the binary tree comes back to the host: it is checked like a host-built one (automatic mode: the culling relies on containment) and made 4-wide there
         std::vector<DevNode> rn ( built_nodes );
         HIP_TRY ( hipMemcpy ( rn.data(), base + o_fn, rn.size() * sizeof ( DevNode ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
-        if ( s->tree_mode == 2 || s->reach || getenv ( "TERRA_AMD_VERIFY_DEVICE_TREE" ) ) {
+        {   // (every device-built tree is checked, whatever the tree mode: the read-back is needed for the wide nodes anyway)
             std::vector<DevTri> rt ( ntri );
             HIP_TRY ( hipMemcpy ( rt.data(), base + o_ft, rt.size() * sizeof ( DevTri ), hipMemcpyDeviceToHost ), kTerraAmdErrNoDevice );
             std::vector<TerraAABB> leaf_boxes ( ntri );
@@ -1245,6 +1266,10 @@ static int fill_params ( Scene* s, const TerraCamera* cam, size_t fb_w, size_t f
     // automatic mode: the containment argument also needs the ray origins (the camera) inside the verified coordinate range
     const bool cam_ok = ( s->reach || s->reach_cull ) ? ( fabsf ( p.cam_pos[0] ) <= s->reach_limit && fabsf ( p.cam_pos[1] ) <= s->reach_limit && fabsf ( p.cam_pos[2] ) <= s->reach_limit ) : coords_within_margin ( p.cam_pos, 3 );
     if ( s->use_fast && s->dev.fast_nodes_h && ( s->tree_mode == 1 || cam_ok ) ) terra_plan_fast_tree ( p );
+    else if ( ( s->use_fast || s->cull_ok ) && !cam_ok && !s->warned_camera.exchange ( true ) )          // (once per scene)
+        fprintf ( stderr, "[terra_amd] warning: camera at (%g, %g, %g) lies outside the range (+-%g) for which this scene's traversal shortcut is proven: this call runs the reference "
+                  "tree's replica traversal (same image, typically 10-20 x slower on large scenes); terra_amd_traversal_info() reports camera_limit and last_call\n",
+                  ( double ) p.cam_pos[0], ( double ) p.cam_pos[1], ( double ) p.cam_pos[2], ( double ) ( ( s->reach || s->reach_cull ) ? s->reach_limit : TERRA_CULL_MAX_COORD ) );
     if ( s->test_fast_stack_lds > 0 && p.lds_mode == 2 ) {      // TEST HOOK: a short LDS column, so that ordinary scenes exercise the HBM part of the stack
         const uint32_t need = p.stack_depth + p.spill_cap;
         p.stack_depth = need < ( uint32_t ) s->test_fast_stack_lds ? need : ( uint32_t ) s->test_fast_stack_lds; p.spill_cap = need - p.stack_depth;
@@ -1325,9 +1350,14 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     const size_t spill_bytes = terra_fast_spill_bytes ( p );                 // fast-tree launches: the part of the lanes' traversal stacks that does not live in LDS
     const size_t scratch_bytes = header + partial_bytes + stream_bytes + spill_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)][stack spill (fast tree)]
     // (a thread's slot keeps scratch for tile-sized calls only: a full-frame call's gigabytes come from, and go back to, the device's pool)
+    // a launch's scratch is bounded: 48 bytes per (pixel, lane-per-pixel) job on LDS-resident scenes -- a 4K frame at 64 lanes per pixel asks for 25 GB per concurrent stream.
+    // Beyond TERRA_SCRATCH_MAX_GB the call is refused with the size in the message (fewer lanes per pixel, or the frame in several calls, give the same framebuffer)
+    if ( scratch_bytes > ( size_t ) TERRA_SCRATCH_MAX_GB << 30 )
+        return fail ( kTerraAmdErrBadArgument, "this launch needs %.1f GB of scratch (%u blocks x sample split %u: 16 B of job sums%s per job), more than the %d GB a launch may take: lower terra_amd_set_sample_split or render the frame in several calls",
+                      ( double ) scratch_bytes / ( 1 << 30 ), blocks, split, stream_bytes ? " + 32 B of job streams" : "", TERRA_SCRATCH_MAX_GB );
     void* scratch = ( slot && scratch_bytes <= ( size_t ( 256 ) << 20 ) ) ? slot_scratch ( slot, scratch_bytes ) : nullptr;
     const bool pooled = scratch == nullptr;
-    if ( pooled ) HIP_TRY ( hipMallocAsync ( &scratch, scratch_bytes, stream ), kTerraAmdErrNoDevice );
+    if ( pooled ) { const hipError_t ea = hipMallocAsync ( &scratch, scratch_bytes, stream ); if ( ea != hipSuccess ) { ( void ) hipGetLastError(); return fail ( kTerraAmdErrNoDevice, "launch scratch of %.2f GB: %s", ( double ) scratch_bytes / ( 1 << 30 ), hipGetErrorString ( ea ) ); } }
     // the queue word must be zero when the render kernel starts: a slot's scratch is zeroed when it is allocated and again by every resolve kernel (one kernel less per
     // call on the host path, whose small kernels wait behind the other callers' render grids); memory from the pool is fresh each time
     hipError_t e = pooled ? hipMemsetAsync ( scratch, 0, header, stream ) : hipSuccess;
@@ -1451,10 +1481,14 @@ struct ThreadSlot {
 // clients that start fresh worker threads for every frame would otherwise pay a stream creation, three allocations and -- worse -- three hipFree, each of which
 // waits for the whole device, per thread and frame. The pool is emptied when the library is unloaded.
 // Hardware queues: ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and kernels of streams that share one run one after the other.
-// The reference's client calls terra_render() from 8 worker threads (satellite/src/Renderer.cpp:70-98), each with its own stream here, so the library asks for 8 when it is
-// loaded -- which only has an effect if that happens before the process's first HIP call, and never overrides a value the user has set (tile loop of the Cornell
-// frame, 8 threads: 69.7 -> 65.5 ms; profiles/r03_measurements/host_tile_loop.log).
-__attribute__ (( constructor )) static void terra_amd_ask_for_hw_queues() { setenv ( "GPU_MAX_HW_QUEUES", "8", 0 ); }
+// The reference's client calls terra_render() from 8 worker threads (satellite/src/Renderer.cpp:70-98), each with its own stream here, so such a client wants 8 -- which
+// only has an effect when the variable is set before the process's first HIP call (tile loop of the Cornell frame, 8 threads: 69.7 -> 65.5 ms;
+// profiles/r03_measurements/host_tile_loop.log). A library does not change its host's environment behind its back: terra_amd_init() does it when the CLIENT asks, first
+// thing in main(); it never overrides a value the user has set.
+extern "C" int terra_amd_init ( void ) {
+    if ( setenv ( "GPU_MAX_HW_QUEUES", "8", 0 ) != 0 ) return fail ( kTerraAmdErrBadArgument, "setenv failed" );
+    return 0;
+}
 struct SlotPool {
     std::mutex lock; std::vector<ThreadSlot*> idle;
     ThreadSlot* take() { std::lock_guard<std::mutex> g ( lock ); if ( idle.empty() ) return new ThreadSlot(); ThreadSlot* t = idle.back(); idle.pop_back(); return t; }

@@ -594,7 +594,11 @@ TD void fast_push ( const Tracer& T, int*& top, uint32_t v ) {
 TD uint32_t fast_pop ( const Tracer& T, int*& top ) {
     top -= TERRA_COL;
     const uint32_t a = ( uint32_t ) ( uintptr_t ) top;
-    return __builtin_expect ( a < T.stack_lim, 1 ) ? ( uint32_t ) * top : T.spill[ ( a - T.stack_lim ) >> 10];
+    // (the LDS side is read through an LDS-typed pointer: left as two loads of generic pointers, the compiler merges them into ONE flat load of a selected address -- and a
+    //  flat load goes through the texture addresser, the unit these kernels are short of, instead of the LDS pipeline)
+    typedef const __attribute__ (( address_space ( 3 ) )) uint32_t* LdsPtr;
+    if ( __builtin_expect ( a < T.stack_lim, 1 ) ) return * ( LdsPtr ) ( uintptr_t ) a;
+    return T.spill[ ( a - T.stack_lim ) >> 10];
 }
 // compare-exchange of two (key, child word) pairs: afterwards a holds the smaller key
 TD void order_pair ( uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb ) {
@@ -856,6 +860,32 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
         if ( COUNT == 2 ) c.attr_fetches += nattr + 1;
     }
     return res;
+}
+
+// terra_scene_raycast for a ray of which only "which triangle is hit first" matters (the shadow ray of the Direct integrator, src/Terra.c:1349-1426, on scenes whose
+// emissive attributes are constants): same traversal, same counts -- a hit is a surface initialisation in the reference -- without setting the surface up.
+// Returns the triangle's index in the soup (the index the light tables use), 0xffffffff for a miss.
+template <int COUNT, int MODE>
+TD uint32_t scene_raycast_triangle ( const Tracer& T, const Ray& in, Counters& c ) {
+    Ray r = in;
+    r.o = r.o + r.d * 0.001f;
+    RayState st = ray_state_init ( r );
+    if ( COUNT ) ++c.rays;
+    uint32_t tri;
+    if ( MODE >= 2 ) { const ClosestRanked b2 = bvh_traverse_fast<COUNT, MODE == 3> ( T, r, st, c ); tri = b2.tri; }
+    else tri = bvh_traverse<COUNT, MODE> ( T, r, st, c ).tri;
+    if ( tri == 0xffffffffu ) return tri;
+    uint32_t object;
+    if ( MODE == 1 ) object = __float_as_uint ( T.l_tris[12 * tri + 3] );
+    else {
+        const float4* tris = reinterpret_cast<const float4*> ( MODE >= 2 ? T.sc.fast_tris : T.sc.tris );
+        const float4 t0 = tris[3 * tri];
+        object = __float_as_uint ( t0.w );
+        if ( MODE >= 2 ) tri = T.sc.mats[object].first_tri + __float_as_uint ( tris[3 * tri + 1].w );      // back to the soup index
+    }
+    if ( COUNT ) ++c.hits;
+    if ( COUNT == 2 ) c.attr_fetches += T.l_mats[object].attributes_count + 1;
+    return tri;
 }
 
 TD Ray surface_ray ( const Surface& sf, V3 p, V3 d, float sign ) {
@@ -1156,12 +1186,13 @@ TD V3 integrate_direct ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughpu
 // are kept: `hid` (light sample not visible) and `vis` (visible). Valid for scenes without textured attributes, where the
 // emissive the shadow ray's surface_init would read is the light material's constant.
 struct DirectPending { V3 vis, hid; uint32_t expected; };
-template <int COUNT, int KINDS>
+// MODE: where the light's triangle, the materials and the areas are read from (1: the block's LDS copies, through T.l_*)
+template <int COUNT, int KINDS, int MODE = 0>
 TD DirectPending direct_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c, Ray& shadow_ray ) {
     const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
     if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
-    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    LightSample ls = draw_light_sample<COUNT, MODE> ( sc, rb, c, &T );
     V3 p_to_light = ls.pos - p;
     V3 wi = normalize ( p_to_light );
     shadow_ray = surface_ray ( sf, p, wi, 1.f );
@@ -1170,8 +1201,8 @@ TD DirectPending direct_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 
     float cosv = dot ( neg ( wi ), ls.norm );
     if ( cosv > 0 ) {
         V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
-        float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[ls.tri] );
-        V3 Ld = had ( v3p ( sc.mats[ls.light_object].emissive ), f );
+        float pdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * T.l_area[ls.tri] );
+        V3 Ld = had ( v3p ( T.l_mats[ls.light_object].emissive ), f );
         Ld = Ld * ( dot ( wi, sf.normal ) / ( pdf * ls.pick_pdf ) );
         d.vis = had ( Lo + Ld, throughput );
     }
@@ -1184,14 +1215,14 @@ TD DirectPending direct_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 
 // need from the shaded surface. mis_finish_b applies job B's hit to the running sum exactly as integrate_mis does.
 // Job A's visible term uses the light material's constant emissive: valid for scenes without textured attributes.
 struct MisPending { V3 a_vis, a_hid; uint32_t expected; V3 f2; float bpdf2, cos2; V3 p; uint32_t light_object; V3 t_before; };
-template <int COUNT, int KINDS>
+template <int COUNT, int KINDS, int MODE = 0>
 TD MisPending mis_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throughput, uint32_t bounce, Pcg32& rb, Counters& c, Ray& ray_a, V3& dir_b ) {
     const DevScene& sc = T.sc;
     V3 Lo = v3 ( 0, 0, 0 );
     if ( bounce == 0 && dot ( wo, sf.normal ) > 0 ) Lo = Lo + sf.emissive;
     float e1 = randf ( rb, c, COUNT ), e2 = randf ( rb, c, COUNT ), e3 = randf ( rb, c, COUNT );
     V3 bsdf_dir = bsdf_sample<KINDS> ( sf, e1, e2, e3, wo, azimuth_fetch ( sc.sincos24, e2 ) );
-    LightSample ls = draw_light_sample<COUNT> ( sc, rb, c );
+    LightSample ls = draw_light_sample<COUNT, MODE> ( sc, rb, c, &T );
     MisPending m;
     m.a_hid = Lo; m.a_vis = Lo; m.expected = ls.tri; m.p = p; m.light_object = ls.light_object; m.t_before = throughput;
     {
@@ -1201,11 +1232,11 @@ TD MisPending mis_prepare ( const Tracer& T, Surface& sf, V3 p, V3 wo, V3 throug
         float cosv = dot ( ls.norm, neg ( wi ) );
         if ( cosv > 0 ) {
             float bpdf = bsdf_pdf<KINDS> ( sf, wi, wo );
-            float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * sc.tri_area[ls.tri] );
+            float lpdf = dot ( p_to_light, p_to_light ) / fabsf ( cosv * T.l_area[ls.tri] );
             float weight = ( lpdf * lpdf ) / ( lpdf * lpdf + bpdf * bpdf );
             if ( lpdf != 0 ) {
                 V3 f = bsdf_eval<KINDS> ( sf, wi, wo );
-                V3 L = had ( v3p ( sc.mats[ls.light_object].emissive ), f );
+                V3 L = had ( v3p ( T.l_mats[ls.light_object].emissive ), f );
                 L = L * ( dot ( wi, sf.normal ) * weight / ( lpdf * ls.pick_pdf ) );
                 m.a_vis = Lo + L;
             }
@@ -1225,7 +1256,7 @@ TD V3 mis_finish_b ( const Tracer& T, const MisPending& m, V3 Lo, bool hit, uint
         if ( NoW > 0 ) {
             V3 dl = m.p - hit_point;
             float dist = dot ( dl, dl );
-            const float4* tris = reinterpret_cast<const float4*> ( T.sc.tris );
+            const float4* tris = MODE == 1 ? reinterpret_cast<const float4*> ( T.l_tris ) : reinterpret_cast<const float4*> ( T.sc.tris );      // (hit_tri: index in the soup)
             float4 t0 = tris[3 * hit_tri + 0], t1 = tris[3 * hit_tri + 1], t2 = tris[3 * hit_tri + 2];
             float area = triangle_area ( v3 ( t0.x, t0.y, t0.z ), v3 ( t1.x, t1.y, t1.z ), v3 ( t2.x, t2.y, t2.z ) );
             float lpdf = dist / ( NoW * area );

@@ -251,7 +251,7 @@ Built build ( std::vector<Prim>& prims ) {
         if ( n >= 20000 ) {
             cpu_set_t set; CPU_ZERO ( &set );
             int cpus = sched_getaffinity ( 0, sizeof set, &set ) == 0 ? CPU_COUNT ( &set ) : ( int ) std::thread::hardware_concurrency();
-            if ( const char* e = getenv ( "TERRA_AMD_BUILD_THREADS" ) ) cpus = atoi ( e );
+            if ( const int asked = terra_build_threads() ) cpus = asked;          // terra_amd_set_build_threads
             n_threads = std::max ( 1, std::min ( cpus, 16 ) );
         }
         auto run = [&] ( bool refine, int depth_cap ) {
@@ -308,7 +308,7 @@ Built build ( std::vector<Prim>& prims ) {
         };
         todo.push_back ( { 0, mid, 0, 0, 1 } );
         todo.push_back ( { mid, n, 0, 1, 1 } );
-        const bool timing = getenv ( "TERRA_AMD_TIMING" ) != nullptr;
+        const bool timing = terra_commit_timing_on();
         auto now = [] { return std::chrono::duration<double> ( std::chrono::steady_clock::now().time_since_epoch() ).count(); };
         double t0 = now();
         run ( false, 0 );

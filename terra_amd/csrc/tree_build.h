@@ -10,6 +10,9 @@
 struct HostNode { TerraAABB aabb[2]; int32_t index[2]; int32_t type[2]; };   // reference node layout (src/TerraBVH.h:13-17)
 static_assert ( sizeof ( HostNode ) == 64, "reference node is 64 bytes" );
 
+int  terra_build_threads();          // scene_host.cpp: terra_amd_set_build_threads (0 = automatic)
+bool terra_commit_timing_on();       // scene_host.cpp: terra_amd_set_commit_timing
+
 namespace bvh {
 TerraAABB empty_box();
 void grow_by_triangle ( TerraAABB& box, const TerraTriangle& t );      // union with the triangle's box, inflated by 1e-4 as the reference does

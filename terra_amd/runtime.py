@@ -68,6 +68,10 @@ _EXTRA = {
     "terra_amd_debug_pad_stack": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_debug_fast_stack_lds": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_scene_supported": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "terra_amd_init": (C.c_int, []),
+    "terra_amd_set_commit_timing": (None, [C.c_int]),
+    "terra_amd_set_build_threads": (C.c_int, [C.c_int]),
+    "terra_amd_set_azimuth_table": (None, [C.c_int]),
     "terra_amd_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "terra_amd_get_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "terra_amd_shard_owner": (C.c_int, [C.c_size_t, C.c_int]),
@@ -117,7 +121,8 @@ def load(need_torch: bool = True) -> api.TerraLib:
     if lib.missing:
         raise TerraAmdError(f"{LIB_PATH} lacks Terra.h entry points: {lib.missing}")
     for name, (res, args) in _EXTRA.items():
-        setattr(lib, name[len("terra_amd_"):] if name.startswith("terra_amd_") else name, lib.fn(name, res, args))
+        if lib.has(name):          # (an older build of the library, loaded through TERRA_AMD_LIB for an A/B, lacks the newer entry points: calling one then fails by name)
+            setattr(lib, name[len("terra_amd_"):] if name.startswith("terra_amd_") else name, lib.fn(name, res, args))
     _lib = lib
     return lib
 

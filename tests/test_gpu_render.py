@@ -527,9 +527,8 @@ def test_host_fast_tree_build_does_not_depend_on_its_threads(H, L, monkeypatch):
     import torch
     d = scenes.sponza_hall(160, 90, 2, integrator=0)
     got = []
-    for threads in ("1", "3", None, None):
-        if threads is None: monkeypatch.delenv("TERRA_AMD_BUILD_THREADS", raising=False)
-        else: monkeypatch.setenv("TERRA_AMD_BUILD_THREADS", threads)
+    for threads in (1, 3, 0, 0):           # terra_amd_set_build_threads (0 = every core the process may use)
+        runtime.check(L.set_build_threads(threads))
         scene = scenes.build_scene(L, d, tree_mode=1, tree_builder=0)
         fb = runtime.DeviceFramebuffer(d.width, d.height)
         runtime.render_device(L, scenes.camera_of(d), scene, fb); torch.cuda.synchronize()

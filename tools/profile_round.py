@@ -40,6 +40,9 @@ PASSES = {
     "sq2": ["SQ_THREAD_CYCLES_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_BRANCH", "SQ_WAIT_INST_ANY"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
+    # dynamic VALU instruction mix by class (bench.valu_mix_ceiling prices it with the measured per-class issue cycles)
+    "mix1": ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"],
+    "mix2": ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_ADD_F16", "SQ_INSTS_VALU_MUL_F16", "SQ_INSTS_VALU_FMA_F16", "SQ_INSTS_VALU_TRANS_F16"],
 }
 # passes for the workloads that read the scene from global memory (what binds a divergent gather: wave stalls, the texture addresser, the L1 tags, the L2): collected
 # like the others, each in its own run. TA / TCP / TCC counters are summed over their instances (the `_sum` derived names).
@@ -109,6 +112,7 @@ def main():
     if "gather" in names:
         names = [n for n in names if n != "gather"] + list(GATHER_PASSES)
     passes = {n: allp[n] for n in names} if names else PASSES
+    auto_gather = not names          # default invocation: the workloads read from global memory also get the gather passes
     for wl, tree, integ, split, extra in CONFIGS:
         key = bench.pmc_key(wl, tree, integ, split, 0)
         if a.only and a.only not in key:
@@ -142,7 +146,10 @@ def main():
         allc = {}; meta_r = {}; per_kernel = {}
         if key in result:            # passes of an earlier run (other pass names) are kept
             allc.update({k: v for k, v in result[key].get("pmc", {}).items()})
-        for pname, ctrs in passes.items():
+        these = dict(passes)
+        if auto_gather and "fast tree" in rec["traversal"] or (auto_gather and "replica" in rec["traversal"] and "hall" in wl):
+            these.update(GATHER_PASSES)
+        for pname, ctrs in these.items():
             if not a.reaggregate:
                 rc, so = run(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", str(d / pname), "--", "python3"] + args, d / f"{pname}.err")
                 if rc != 0:
@@ -171,6 +178,11 @@ def main():
             rec["hbm_bytes_per_launch"] = int((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024)
         rec["resources"] = meta_r or result.get(key, {}).get("resources", {})
         rec["pmc"] = dict(allc)      # every counter collected for the timed kernel, per launch (all passes so far)
+        static = {}
+        for sf in sorted((ROOT / "profiles").glob("r[0-9][0-9]_static_valu_mix.json")):
+            static = json.loads(sf.read_text())
+        if rec.get("kernel_name") in static:      # tools/valu_mix.py: the issue cost of the opcodes the class counters do not name, from this kernel's ISA
+            rec["other_cycles"] = static[rec["kernel_name"]]["other_cycles"]
         for k2 in ("hbm_bytes_per_launch", "fetch_size_kb", "write_size_kb", "lane_util", "lds_bank_conflict_frac", "waves_per_simd", "kernel_name"):
             if k2 not in rec and k2 in result.get(key, {}):
                 rec[k2] = result[key][k2]

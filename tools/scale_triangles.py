@@ -1,12 +1,12 @@
 """Throughput against scene size: the procedural hall at rising tessellation (97k .. 650k triangles), fast tree built on the
 host (binned SAH) and on the device (LBVH), Simple integrator, 1920x1080 x 16 spp; also the commit time and its phases
-(TERRA_AMD_TIMING=1 prints them on stderr). One GPU."""
+(terra_amd_set_commit_timing(1) prints them on stderr). One GPU."""
 import torch  # first
 import ctypes as C, os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from terra_amd import api, runtime, scenes
 lib = runtime.load()
-os.environ.setdefault("TERRA_AMD_TIMING", "1")
+lib.set_commit_timing(1)
 for detail, builder in [(dt, b) for dt in (1.0, 2.0, 3.2) for b in (0, 1)]:
     d = scenes.sponza_hall(1920, 1080, 16, detail=detail)
     t = time.perf_counter(); s = scenes.build_scene(lib, d, tree_mode=2, tree_builder=builder); commit = time.perf_counter() - t
