@@ -433,7 +433,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
     const int tid = threadIdx.x;
     Tracer T0 = make_tracer<MODE> ( p.scene, lds_f4, p.stack_depth, p.leaf_cap, p.lds_nodes, p.lds_tris, p.leaf_cull != 0, p.fused_slab != 0 );
     T0.faults = p.counters + kCtrFaults;
-    if ( MODE >= 2 && p.stack_spill ) { T0.spill = p.stack_spill + ( size_t ) ( blockIdx.x * 256u + threadIdx.x ) * p.spill_cap; T0.spill_cap = p.spill_cap - TERRA_CHECK_SHRINK; }
+    if ( MODE >= 2 && p.stack_spill ) { T0.spill = p.stack_spill + ( size_t ) ( blockIdx.x * 256u + threadIdx.x ) * p.spill_cap; T0.spill_cap = p.spill_cap; }
     const Tracer T = T0;
 
     PixelStreams rs = trng_pixel_streams ( 0, 0, 0 );

@@ -583,6 +583,8 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 //  and t * 4 < 1024, so address < base + cap * 1024 exactly when e < cap; the HBM index is computed on the cold side only)
 TD void fast_push ( const Tracer& T, int*& top, uint32_t v ) {
     const uint32_t a = ( uint32_t ) ( uintptr_t ) top;
+    // (bounds-checking builds: an entry beyond what the host planned -- LDS column + HBM part, the positive control's shrink taken off the column -- is refused and counted)
+    if ( TERRA_CHECK_BOUNDS && ( int ) ( top - T.stack ) / TERRA_COL >= T.stack_cap + ( int ) T.spill_cap ) { if ( T.faults ) atomicAdd ( T.faults, 1ull ); return; }
     if ( __builtin_expect ( a < T.stack_lim, 1 ) ) *top = ( int ) v;
     else {
         const uint32_t k = ( a - T.stack_lim ) >> 10;

@@ -74,6 +74,8 @@ for it in range(n_iter):
     for tree in (0, 1, 2):
         lib.clear_error()
         s = scenes.build_scene(lib, d, tree_mode=tree); runtime.check(lib.set_sample_split(s, split))
+        if tree and hasattr(lib, "debug_fast_stack_lds"):      # the fast tree's stack: sometimes only 1-3 entries in LDS, so that the HBM part is exercised (the image must not change)
+            runtime.check(lib.debug_fast_stack_lds(s, int(rs.choice([0, 0, 1, 2, 3]))))
         fb = runtime.DeviceFramebuffer(W, H)
         runtime.check(lib.render_device(C.byref(cam), s, fb.pixels.data_ptr(), fb.results.data_ptr(), W, H, 0, 0, W, H, None, None))
         torch.cuda.synchronize()
