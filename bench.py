@@ -318,8 +318,18 @@ VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.55, "SQ_INSTS_VALU_MUL_F32": 2.4
                      "SQ_INSTS_VALU_ADD_F16": 4.2, "SQ_INSTS_VALU_MUL_F16": 4.2, "SQ_INSTS_VALU_FMA_F16": 4.2, "SQ_INSTS_VALU_TRANS_F16": 8.1}
 
 
-def valu_mix_ceiling(rec):
-    """fraction of the nominal VALU issue peak (2 cycles per wave64 instruction) that this kernel's DYNAMIC instruction mix can reach at most: total / sum(class count x class cycles) x 2"""
+# What a MIX of instruction classes can issue, measured: synthetic streams of independent instructions with the kernels' class proportions, 5 waves per SIMD on every CU
+# (tools/ubench/valu_rates.hip `mix`, profiles/r04_measurements/valu_mix_rates.log), in G wave64 instructions per second per SIMD:
+#   the headline kernel's dynamic mix (add 12 %, mul 15 %, fma 20 %, transcendental 2 %, integer 17 %, compares / selects / min-max / moves 32 %)   0.936  = 2.56 cycles
+#   the fast tree's 4-wide node step (v_fma_mix_f32, v_perm_b32, min / max, compares, selects, integer min / max)                                  0.702  = 3.42 cycles
+# The sum of the pure-stream costs of the same instructions (the additive model below) says 3.53 cycles for the first mix: classes overlap in issue, pure-stream rates do not add.
+MIX_CEILING_GINST_PER_SIMD = {"lds_resident": 0.936, "fast_tree": 0.702}
+
+
+def valu_mix_ceiling(rec, lds_resident=True):
+    """The VALU issue ceiling of this kind of kernel's instruction mix as a fraction of the nominal peak (2 cycles per wave64 instruction): `frac_of_peak` from the measured mixed
+    stream (above); `additive_model` = total / sum(class count x pure-stream class cycles) x 2 from the kernel's own dynamic class counters, kept beside it because it is the
+    model the round-3 notes used -- the kernels issue FASTER than it allows, which is what shows that it is not a ceiling"""
     pmc = rec.get("pmc", {})
     total = pmc.get("SQ_INSTS_VALU") or rec.get("SQ_INSTS_VALU")
     named = {k: pmc[k] for k in VALU_CLASS_CYCLES if k in pmc}
@@ -327,7 +337,10 @@ def valu_mix_ceiling(rec):
         return None
     other = max(0.0, total - sum(named.values()))
     cycles = sum(v * VALU_CLASS_CYCLES[k] for k, v in named.items()) + other * float(rec.get("other_cycles", 4.1))
-    return {"frac_of_peak": round(2.0 * total / cycles, 4), "mean_cycles_per_instr": round(cycles / total, 3), "other_share": round(other / total, 4),
+    kind = "lds_resident" if lds_resident else "fast_tree"
+    g = MIX_CEILING_GINST_PER_SIMD[kind]
+    return {"frac_of_peak": round(g * 1024 / VALU_PEAK_GINST, 4), "measured_stream": kind, "ginst_per_simd": g, "source": "profiles/r04_measurements/valu_mix_rates.log",
+            "additive_model": {"frac_of_peak": round(2.0 * total / cycles, 4), "mean_cycles_per_instr": round(cycles / total, 3)}, "other_share": round(other / total, 4),
             "classes": {k.replace("SQ_INSTS_VALU_", ""): round(v / total, 4) for k, v in named.items() if v}}
 
 
@@ -352,7 +365,7 @@ def roofline(key, st, kernel_ms, lds_resident, world, pmc=None):
     fabric = traffic / t / 1e9 if traffic else None                # GB/s the L2 moved on its fabric side
     valu_frac = round(valu / VALU_PEAK_GINST, 4) if valu else None
     fabric_frac = round(fabric / HBM_PEAK_GBS, 4) if fabric else None
-    mix = valu_mix_ceiling(rec) if rec else None
+    mix = valu_mix_ceiling(rec, lds_resident) if rec else None
     out.update({"traffic": traffic, "valu_insts_per_launch": insts, "lane_util": rec.get("lane_util"), "lds_bank_conflict_frac": rec.get("lds_bank_conflict_frac"),
                 "valu_frac": valu_frac, "l2_fabric_frac": fabric_frac})
     if mix:
@@ -392,7 +405,7 @@ def roofline(key, st, kernel_ms, lds_resident, world, pmc=None):
         out.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": None})
     if lds_resident:
         out["note"] = ("scene staged in LDS: the kernel is bound by VALU issue. achieved = SQ_INSTS_VALU (profiles/rNN_pmc.json) / kernel time measured in this run; peak = 1024 SIMD x 2.4 GHz / 2 cycles. "
-                       "valu_mix_ceiling = what the kernel's dynamic instruction mix (SQ_INSTS_VALU_* counters x the measured per-class issue cycles, profiles/r02_measurements/valu_rates.log) can reach of that peak; "
+                       "valu_mix_ceiling.frac_of_peak = what a stream with this kernel's dynamic class mix (SQ_INSTS_VALU_* counters) issues at most, measured (profiles/r04_measurements/valu_mix_rates.log); "
                        "lane_util says how many of the issued lanes did work; `traffic` is what the L2 moved on its fabric side")
     else:
         out["note"] = ("scene read from global memory (L2 / Infinity Cache resident). Three resources are close to their limits together and `bound` names the closest: VALU issue against the ceiling of "

@@ -116,7 +116,9 @@ def test_two_gloo_ranks_on_one_gpu_started_by_bench_itself():
 
 
 def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
-    """roofline.frac = SQ_INSTS_VALU / kernel time / (1024 SIMDs x 2.4 GHz / 2) -- or fabric bytes / kernel time / 8 TB/s when that is larger -- from the newest profiles/rNN_pmc.json"""
+    """roofline.frac = the counter the bound names / kernel time / that resource's peak, from the newest profiles/rNN_pmc.json: VALU issue (SQ_INSTS_VALU against 1024 SIMDs x
+    2.4 GHz / 2), the texture addresser (TA_TA_BUSY_sum against 256 x 2.4 GHz), the L1 <- L2 gather (TCP_TCC_READ_REQ_sum x 128 B against 16.8 TB/s) or the L2's fabric side
+    (bytes against 8 TB/s); `bound` is the largest -- VALU issue compared through the ceiling of the kernel's dynamic instruction mix when the class counters are there"""
     import bench
     f = bench.pmc_file()
     assert f is not None and f.parent == ROOT / "profiles"
@@ -125,11 +127,19 @@ def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
     for key, rec in pmc.items():
         r = bench.roofline(key, rec["counters_per_launch"], rec["kernel_ms"], "cornell" in key, 1)
         t = rec["kernel_ms"] * 1e-3
-        valu = rec["SQ_INSTS_VALU"] / t / 1e9 / (1024 * 2.4 / 2)
-        fabric = rec["hbm_bytes_per_launch"] / t / 1e9 / 8000.0
-        assert r["pmc_record"] == key and 0 < r["frac"] <= 1 and r["bound"] in ("valu", "l2_fabric")
-        assert abs(r["frac"] - max(valu, fabric)) < 1e-3 and (r["bound"] == "valu") == (valu >= fabric or abs(valu - fabric) < 1e-3)
-        assert 0 < r["lane_util"] <= 1 and r["algorithmic_gbs"] > 0
+        c = rec.get("pmc", {})
+        fr = {"valu": (rec.get("SQ_INSTS_VALU") or c["SQ_INSTS_VALU"]) / t / 1e9 / (1024 * 2.4 / 2), "l2_fabric": rec["hbm_bytes_per_launch"] / t / 1e9 / 8000.0}
+        if "TA_TA_BUSY_sum" in c:
+            fr["ta"] = c["TA_TA_BUSY_sum"] / t / 1e9 / (256 * 2.4)
+        if "TCP_TCC_READ_REQ_sum" in c:
+            fr["l2_gather"] = c["TCP_TCC_READ_REQ_sum"] * 128.0 / t / 1e9 / 16800.0
+        assert r["pmc_record"] == key and r["bound"] in fr and 0 < r["frac"] <= 1.02
+        assert abs(r["frac"] - fr[r["bound"]]) < 1e-3, (key, r["bound"], r["frac"], fr)
+        assert abs(r["valu_frac"] - fr["valu"]) < 1e-3 and 0 < r["lane_util"] <= 1 and r["algorithmic_gbs"] > 0
+        mix = r.get("valu_mix_ceiling")
+        assert mix and 0.4 < mix["frac_of_peak"] < 1.0 and r["valu_frac_of_mix_ceiling"] < 1.1, (key, mix)
+        if "fast tree" in rec["traversal"]:                               # the global-memory kernels carry the gather evidence
+            assert 0 < r["ta_busy_frac"] <= 1.02 and 0 < r["wave_wait_frac"] < 1 and 0 < r["l2_gather"]["frac"] < 1.2
     hk = bench.pmc_key("cornell_1080p_512spp", "auto", "simple", bench.DEFAULT_SPLIT, 0)          # the headline launch's record
     head = bench.roofline(hk, pmc[hk]["counters_per_launch"], pmc[hk]["kernel_ms"], True, 1)
     assert head["bound"] == "valu" and 0.6 < head["frac"] < 0.8 and head["pmc_file"] == "profiles/" + f.name

@@ -267,3 +267,32 @@ def test_binary16_planes_are_rounded_outward(H, L):
         assert ok.all(), (x[~ok][:5], h[~ok][:5])
     nan = np.array([np.nan]); o = np.zeros(1, np.uint16)
     assert f(nan.ctypes.data, 1, 1, o.ctypes.data) == 0 and o[0] == 0x7c00 and f(nan.ctypes.data, 1, 0, o.ctypes.data) == 0 and o[0] == 0xfc00      # the widest value either way
+
+
+def test_scene_supported_query(H, L):
+    """terra_amd_scene_supported: what the commit would decide about the scene's materials, asked without committing and without touching the error channels -- the reference
+    runs any callback (src/Terra.c:1071-1075, 1804-1810), the device runs the presets and texture lookups only"""
+    d = scenes.cornell_box(8, 8, 1)
+    why = C.create_string_buffer(256)
+    scene = L.scene_create()
+    for od in d.objects:
+        scenes.fill_object(L, L.scene_add_object(scene, len(od.triangles)).contents, od)
+    scenes.apply_options(L, scene, d)
+    L.clear_error(); L.clear_first_error()
+    st = L.scene_supported(scene, why, 256)
+    if L.device_count() > 0:
+        assert st == 0 and why.value == b""
+    else:
+        assert st == -1 and b"no HIP device" in why.value                 # (the only objection on a box without a GPU)
+    extra = L.scene_add_object(scene, 1).contents
+    scenes.fill_object(L, extra, scenes.ObjectDesc(d.objects[0].triangles[:1], d.objects[0].normals[:1], d.objects[0].texcoords[:1]))
+    extra.material.bsdf.pdf = C.cast(L.malloc, C.c_void_p)                 # a client-supplied callback
+    st = L.scene_supported(scene, why, 256)
+    assert st == -3 and b"object 6" in why.value and b"preset" in why.value
+    L.bsdf_diffuse_init(C.byref(extra.material.bsdf))
+    extra.material.attributes[0].state = C.cast(L.malloc, C.c_void_p); extra.material.attributes[0].eval = C.cast(L.malloc, C.c_void_p)      # an attribute callback
+    st = L.scene_supported(scene, why, 256)
+    assert st == -3 and b"attribute 0" in why.value and b"terra_texture_sample" in why.value
+    assert L.scene_supported(scene, None, 0) == -3                           # the reason is optional
+    assert runtime.last_error() == "" and runtime.first_error() == (0, "")   # a pure query: nothing recorded
+    L.scene_destroy(scene)

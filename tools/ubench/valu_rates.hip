@@ -68,6 +68,15 @@ __global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float s
 #define I_BFE(i) asm volatile ( "v_bfe_u32 %0, %0, 3, 5" : "+v"( u[i] ) );
 #define I_ADDC(i) asm volatile ( "v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"( u[i] ) : "v"( ub ) : "vcc" );
 #define S_SALU(i) asm volatile ( "s_add_u32 s20, s20, 1" : : : "s20" );
+#define F_MIX(i) asm volatile ( "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"( a[i] ) : "v"( u[i] ), "v"( b ) );
+#define V_PERM(i) asm volatile ( "v_perm_b32 %0, %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_MINU(i) asm volatile ( "v_min_u32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+#define I_MAXU(i) asm volatile ( "v_max_u32 %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
+        // mixed streams, 48 instructions per iteration (cycles per instruction are then printed for 16 x 3 = 48): the DYNAMIC class mix of the headline kernel
+        // (SQ_INSTS_VALU_* counters, profiles/r04_pmc.json: add 12 %, mul 15 %, fma 20 %, transcendental 2 %, integer 17 %, the rest compares / selects / min-max / moves)
+        // and the instruction mix of the fast tree's 4-wide node step (v_fma_mix_f32, v_perm_b32, min / max, compares, selects, the sorting network's integer min / max)
+        if ( OP == 100 ) { for ( int rep = 0; rep < 1; ++rep ) { F_ADD ( 0 ) F_MUL ( 1 ) F_FMA ( 2 ) I_CMPS ( 3 ) F_FMA ( 4 ) I_ADD ( 5 ) C_SGPR ( 6 ) F_MUL ( 7 ) F_FMA ( 8 ) V_MOV ( 9 ) F_ADD ( 10 ) I_AND ( 11 ) F_FMA ( 12 ) F_MIN3 ( 13 ) F_MUL ( 14 ) I_CMPS ( 15 ) F_FMA ( 0 ) I_LSHLADD ( 1 ) C_SGPR ( 2 ) F_ADD ( 3 ) F_MUL ( 4 ) F_FMA ( 5 ) I_ADD ( 6 ) I_CMPS ( 7 ) F_RCP ( 8 ) F_FMA ( 9 ) V_MOV ( 10 ) F_MUL ( 11 ) I_ADD ( 12 ) F_ADD ( 13 ) C_SGPR ( 14 ) F_FMA ( 15 ) F_MAX ( 0 ) I_CMPS ( 1 ) F_MUL ( 2 ) I_AND ( 3 ) F_FMA ( 4 ) I_LSHR ( 5 ) F_ADD ( 6 ) I_LSHLADD ( 7 ) C_SGPR ( 8 ) F_MUL ( 9 ) F_FMA ( 10 ) V_MOV ( 11 ) I_CMPS ( 12 ) F_ADD ( 13 ) I_ADD ( 14 ) F_MIN3 ( 15 ) } }
+        if ( OP == 101 ) { for ( int rep = 0; rep < 1; ++rep ) { F_MIX ( 0 ) F_MIX ( 1 ) V_PERM ( 2 ) F_MIX ( 3 ) I_CMPS ( 4 ) F_MIX ( 5 ) V_PERM ( 6 ) C_SGPR ( 7 ) F_MIX ( 8 ) F_MIN3 ( 9 ) F_MIX ( 10 ) I_ADD ( 11 ) V_PERM ( 12 ) F_MIX ( 13 ) F_MAX ( 14 ) I_CMPS ( 15 ) F_MIX ( 0 ) C_SGPR ( 1 ) I_MINU ( 2 ) F_MIX ( 3 ) V_PERM ( 4 ) F_MIX ( 5 ) F_MIN3 ( 6 ) I_CMPS ( 7 ) V_MOV ( 8 ) F_MIX ( 9 ) I_MAXU ( 10 ) C_SGPR ( 11 ) V_PERM ( 12 ) I_ADD ( 13 ) F_MAX ( 14 ) I_CMPS ( 15 ) F_MIN3 ( 0 ) C_SGPR ( 1 ) I_MINU ( 2 ) V_MOV ( 3 ) I_LSHL ( 4 ) V_PERM ( 5 ) I_CMPS ( 6 ) C_SGPR ( 7 ) I_ADD ( 8 ) F_MIN3 ( 9 ) I_MAXU ( 10 ) I_AND ( 11 ) V_MOV ( 12 ) I_ADD ( 13 ) I_LSHL ( 14 ) F_MIX ( 15 ) } }
         if ( OP == 0 ) { REP16 ( F_ADD ) }
         if ( OP == 1 ) { REP16 ( F_MUL ) }
         if ( OP == 2 ) { REP16 ( F_FMA ) }
@@ -125,10 +134,11 @@ __global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float s
 }
 
 template <int OP> void run ( const char* name, int waves_per_simd, float* out, double clock_ghz, int cus ) {
-    const int iters = 60000;
+    const int per_iter = OP >= 100 ? 48 : 16;
+    const int iters = OP >= 100 ? 20000 : 60000;
     const int rounds = 6;
     dim3 grid ( cus * waves_per_simd * rounds ), block ( 256 );
-    size_t lds = ( 160 * 1024 ) / waves_per_simd - 512;      // exactly waves_per_simd blocks fit a CU
+    size_t lds = waves_per_simd == 5 ? 31000 : ( 160 * 1024 ) / waves_per_simd - 512;      // exactly waves_per_simd blocks fit a CU (5: the CU does not hand out all of its 160 KB)
     hipEvent_t e0, e1; hipEventCreate ( &e0 ); hipEventCreate ( &e1 );
     static unsigned long long* dc = nullptr; if ( !dc ) hipMalloc ( &dc, 8 );
     hipFuncSetAttribute ( ( const void* ) bench<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 );
@@ -139,8 +149,8 @@ template <int OP> void run ( const char* name, int waves_per_simd, float* out, d
     hipEventRecord ( e1 ); hipEventSynchronize ( e1 );
     float ms; hipEventElapsedTime ( &ms, e0, e1 );
     unsigned long long hc = 0; hipMemcpy ( &hc, dc, 8, hipMemcpyDeviceToHost );
-    double cyc = ( double ) hc / ( ( double ) iters * 16 * waves_per_simd );
-    double ginst = ( double ) iters * 16 * waves_per_simd * rounds / ( ms * 1e-3 ) / 1e9;
+    double cyc = ( double ) hc / ( ( double ) iters * per_iter * waves_per_simd );
+    double ginst = ( double ) iters * per_iter * waves_per_simd * rounds / ( ms * 1e-3 ) / 1e9;
     printf ( "%-14s waves/SIMD %d  %.3f ms  %.3f G wave-instr/s per SIMD = %.2f cycles at 2.4 GHz (one block: %.2f counter ticks per instr)\n", name, waves_per_simd, ms, ginst, 2.4 / ginst, cyc );
 }
 
@@ -149,8 +159,12 @@ int main ( int argc, char** argv ) {
     double ghz = p.clockRate * 1e-6;
     printf ( "%s CUs %d clock %.2f GHz\n", p.name, p.multiProcessorCount, ghz );
     float* out; hipMalloc ( &out, 4 );
-    for ( int w : { 4 } ) {
 #define R(op, n) run<op> ( n, w, out, ghz, p.multiProcessorCount );
+    if ( argc > 1 && std::string ( argv[1] ) == "mix" ) {          // only the mixed streams, at the occupancies the kernels run at
+        for ( int w : { 4, 5 } ) { R ( 100, "mix: headline kernel" ) R ( 101, "mix: 4-wide node step" ) R ( 2, "v_fma_f32" ) R ( 0, "v_add_f32" ) R ( 35, "v_cndmask sgpr" ) }
+        return 0;
+    }
+    for ( int w : { 4 } ) {
         R ( 0, "v_add_f32" ) R ( 1, "v_mul_f32" ) R ( 2, "v_fma_f32" ) R ( 3, "v_min3_f32" ) R ( 4, "v_rcp_f32" ) R ( 5, "v_sqrt_f32" ) R ( 6, "v_rsq_f32" )
         R ( 7, "v_add_f64" ) R ( 8, "v_mul_f64" ) R ( 9, "v_fma_f64" ) R ( 10, "v_rcp_f64" ) R ( 11, "v_cvt_f64_f32" ) R ( 12, "v_cvt_f32_f64" )
         R ( 13, "v_mul_lo_u32" ) R ( 14, "v_mul_hi_u32" ) R ( 15, "v_mad_u64_u32" ) R ( 16, "v_add_u32" ) R ( 17, "v_lshl_add_u32" )  R ( 19, "v_cmp_f32" )
