@@ -29,5 +29,7 @@ hipError_t terra_unit_halton ( int, int, float* ) { return hipErrorNoDevice; }
 hipError_t terra_unit_distribution_1d ( const float*, uint32_t, float*, float*, uint32_t*, const float*, int, float*, float*, uint32_t* ) { return hipErrorNoDevice; }
 hipError_t terra_unit_distribution_2d ( const float*, uint32_t, uint32_t, float*, float*, float*, uint32_t*, const float*, int, float*, float* ) { return hipErrorNoDevice; }
 hipError_t terra_build_fast_tree_device ( const DevTri*, const uint32_t*, uint32_t, float, DevNode*, DevTri*, uint32_t*, int*, hipStream_t ) { return hipErrorNoDevice; }
-hipError_t terra_fast_nodes_center_extent ( DevNode*, uint32_t, hipStream_t ) { return hipErrorNoDevice; }
-void terra_plan_fast_tree ( DevRenderParams& p ) { p.lds_mode = 2; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = 1; p.lds_nodes = 0; }
+void terra_plan_fast_tree ( DevRenderParams& p ) { p.lds_mode = 2; p.lds_tris = 0; p.leaf_cap = 0; p.stack_depth = 1; p.lds_nodes = 0; p.spill_cap = 0; p.stack_spill = nullptr; }
+size_t terra_fast_spill_bytes ( const DevRenderParams& ) { return 0; }
+size_t terra_lds_bytes ( const DevRenderParams& ) { return 0; }
+size_t terra_lds_block_limit ( void ) { return 156 * 1024; }
