@@ -57,7 +57,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime st
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz (MI355X_MICROARCH.md "Execution model")
 TA_PEAK_GCYC = 256 * 2.4              # one texture addresser per CU, 2.4 GHz: G addresser-cycles per second
-L2_GATHER_GBS = 16800.0               # MI355X_MICROARCH.md "Indexed rows": rows gathered from the XCDs' L2, 16.8-18.8 TB/s chip-wide (the lower figure)
+L2_GATHER_GBS = 18800.0               # MI355X_MICROARCH.md "Indexed rows": rows gathered from the XCDs' L2, 16.8-18.8 TB/s chip-wide (the upper figure: the replica kernel moves 17.5)
 TILE = 64
 # Sample split of the timed launches (terra_amd_set_sample_split): the frame equals that of this many successive calls of spp/split samples. With the job queue a
 # launch wants many jobs per resident lane -- at N = 8 a rank renders an eighth of the frame -- and short jobs at its end (Cornell 512 spp: split 8 / 16 / 32 / 64
@@ -323,13 +323,15 @@ VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.55, "SQ_INSTS_VALU_MUL_F32": 2.4
 #   the headline kernel's dynamic mix (add 12 %, mul 15 %, fma 20 %, transcendental 2 %, integer 17 %, compares / selects / min-max / moves 32 %)   0.936  = 2.56 cycles
 #   the fast tree's 4-wide node step (v_fma_mix_f32, v_perm_b32, min / max, compares, selects, integer min / max)                                  0.702  = 3.42 cycles
 # The sum of the pure-stream costs of the same instructions (the additive model below) says 3.53 cycles for the first mix: classes overlap in issue, pure-stream rates do not add.
-MIX_CEILING_GINST_PER_SIMD = {"lds_resident": 0.936, "fast_tree": 0.702}
+# Between and beyond the two measured mixes the ceiling is interpolated by the one thing that separates them -- the share of the 2.3-2.6-cycle instructions (f32 add / mul) in the
+# kernel's dynamic mix: (share, cycles per instruction at 5 waves per SIMD) = (0, 3.42: the node-step stream), (0.27, 2.56: the headline stream), (1, 2.26: a pure v_add_f32 stream)
+MIX_CEILING_POINTS = [(0.0, 3.42), (0.2702, 2.56), (1.0, 2.26)]
 
 
 def valu_mix_ceiling(rec, lds_resident=True):
-    """The VALU issue ceiling of this kind of kernel's instruction mix as a fraction of the nominal peak (2 cycles per wave64 instruction): `frac_of_peak` from the measured mixed
-    stream (above); `additive_model` = total / sum(class count x pure-stream class cycles) x 2 from the kernel's own dynamic class counters, kept beside it because it is the
-    model the round-3 notes used -- the kernels issue FASTER than it allows, which is what shows that it is not a ceiling"""
+    """The VALU issue ceiling of this kernel's dynamic instruction mix as a fraction of the nominal peak (2 cycles per wave64 instruction): `frac_of_peak` from the measured mixed
+    streams (above), interpolated by the kernel's share of f32 add / mul instructions; `additive_model` = total / sum(class count x pure-stream class cycles) x 2 from the same
+    counters, kept beside it because it is the model the round-3 notes used -- the kernels issue FASTER than it allows, which is what shows that it is not a ceiling"""
     pmc = rec.get("pmc", {})
     total = pmc.get("SQ_INSTS_VALU") or rec.get("SQ_INSTS_VALU")
     named = {k: pmc[k] for k in VALU_CLASS_CYCLES if k in pmc}
@@ -337,9 +339,13 @@ def valu_mix_ceiling(rec, lds_resident=True):
         return None
     other = max(0.0, total - sum(named.values()))
     cycles = sum(v * VALU_CLASS_CYCLES[k] for k, v in named.items()) + other * float(rec.get("other_cycles", 4.1))
-    kind = "lds_resident" if lds_resident else "fast_tree"
-    g = MIX_CEILING_GINST_PER_SIMD[kind]
-    return {"frac_of_peak": round(g * 1024 / VALU_PEAK_GINST, 4), "measured_stream": kind, "ginst_per_simd": g, "source": "profiles/r04_measurements/valu_mix_rates.log",
+    share = (pmc.get("SQ_INSTS_VALU_ADD_F32", 0.0) + pmc.get("SQ_INSTS_VALU_MUL_F32", 0.0)) / total
+    pts = MIX_CEILING_POINTS
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if share <= x1:
+            break
+    cyc = y0 + (y1 - y0) * (min(max(share, x0), x1) - x0) / (x1 - x0)
+    return {"frac_of_peak": round(2.0 / cyc, 4), "cycles_per_instr": round(cyc, 3), "add_mul_share": round(share, 4), "source": "profiles/r04_measurements/valu_mix_rates.log",
             "additive_model": {"frac_of_peak": round(2.0 * total / cycles, 4), "mean_cycles_per_instr": round(cycles / total, 3)}, "other_share": round(other / total, 4),
             "classes": {k.replace("SQ_INSTS_VALU_", ""): round(v / total, 4) for k, v in named.items() if v}}
 
@@ -410,7 +416,7 @@ def roofline(key, st, kernel_ms, lds_resident, world, pmc=None):
     else:
         out["note"] = ("scene read from global memory (L2 / Infinity Cache resident). Three resources are close to their limits together and `bound` names the closest: VALU issue against the ceiling of "
                        "the kernel's instruction mix (valu_frac_of_mix_ceiling), the texture addresser (ta_busy_frac: it spends ~21-27 cycles per wave-level load instruction whatever the width, so "
-                       "loads per ray is what counts, not bytes), and the L1 <- L2 line gather against the guide's 16.8 TB/s L2-hit figure (l2_gather); wave_wait_frac = share of wave cycles in s_waitcnt")
+                       "loads per ray is what counts, not bytes), and the L1 <- L2 line gather against the guide's 16.8-18.8 TB/s L2-hit figure (l2_gather, the upper one); wave_wait_frac = share of wave cycles in s_waitcnt")
     return out
 
 

@@ -117,7 +117,7 @@ def test_two_gloo_ranks_on_one_gpu_started_by_bench_itself():
 
 def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
     """roofline.frac = the counter the bound names / kernel time / that resource's peak, from the newest profiles/rNN_pmc.json: VALU issue (SQ_INSTS_VALU against 1024 SIMDs x
-    2.4 GHz / 2), the texture addresser (TA_TA_BUSY_sum against 256 x 2.4 GHz), the L1 <- L2 gather (TCP_TCC_READ_REQ_sum x 128 B against 16.8 TB/s) or the L2's fabric side
+    2.4 GHz / 2), the texture addresser (TA_TA_BUSY_sum against 256 x 2.4 GHz), the L1 <- L2 gather (TCP_TCC_READ_REQ_sum x 128 B against 18.8 TB/s) or the L2's fabric side
     (bytes against 8 TB/s); `bound` is the largest -- VALU issue compared through the ceiling of the kernel's dynamic instruction mix when the class counters are there"""
     import bench
     f = bench.pmc_file()
@@ -132,7 +132,7 @@ def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
         if "TA_TA_BUSY_sum" in c:
             fr["ta"] = c["TA_TA_BUSY_sum"] / t / 1e9 / (256 * 2.4)
         if "TCP_TCC_READ_REQ_sum" in c:
-            fr["l2_gather"] = c["TCP_TCC_READ_REQ_sum"] * 128.0 / t / 1e9 / 16800.0
+            fr["l2_gather"] = c["TCP_TCC_READ_REQ_sum"] * 128.0 / t / 1e9 / 18800.0
         assert r["pmc_record"] == key and r["bound"] in fr and 0 < r["frac"] <= 1.02
         assert abs(r["frac"] - fr[r["bound"]]) < 1e-3, (key, r["bound"], r["frac"], fr)
         assert abs(r["valu_frac"] - fr["valu"]) < 1e-3 and 0 < r["lane_util"] <= 1 and r["algorithmic_gbs"] > 0
