@@ -521,14 +521,15 @@ TD FastRay fast_ray ( const Ray& ray, float inv_scale ) {
     f.px = cx < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP; f.py = cy < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP; f.pz = cz < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP;
     return f;
 }
-// entry distance of one child box from its three plane words (min | max << 16 per axis); hit = the ray's interval inside the box is not empty
-TD bool slab_half ( uint32_t wx, uint32_t wy, uint32_t wz, const FastRay& f, float& t_enter ) {
+// entry distance of one child box from its three plane words (min | max << 16 per axis); hit = the ray's interval inside the box is not empty and starts no later
+// than the closest hit so far. `limit_up` = that hit's depth plus one ulp: t_enter <= depth is t_enter < limit_up, which folds into the min3 of the far planes.
+TD bool slab_half ( uint32_t wx, uint32_t wy, uint32_t wz, const FastRay& f, float limit_up, float& t_enter ) {
     const terra_half2 x = as_half2 ( __builtin_amdgcn_perm ( wx, wx, f.px ) ), y = as_half2 ( __builtin_amdgcn_perm ( wy, wy, f.py ) ), z = as_half2 ( __builtin_amdgcn_perm ( wz, wz, f.pz ) );      // (near, far)
     const float tnx = __builtin_fmaf ( ( float ) x.x, f.inv.x, -f.oi.x ), tfx = __builtin_fmaf ( ( float ) x.y, f.inv.x, -f.oi.x );
     const float tny = __builtin_fmaf ( ( float ) y.x, f.inv.y, -f.oi.y ), tfy = __builtin_fmaf ( ( float ) y.y, f.inv.y, -f.oi.y );
     const float tnz = __builtin_fmaf ( ( float ) z.x, f.inv.z, -f.oi.z ), tfz = __builtin_fmaf ( ( float ) z.y, f.inv.z, -f.oi.z );
     t_enter = __builtin_fmaxf ( __builtin_fmaxf ( __builtin_fmaxf ( tnx, tny ), tnz ), 0.f );
-    return __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz ) > t_enter;
+    return __builtin_fminf ( __builtin_fminf ( __builtin_fminf ( tfx, tfy ), tfz ), limit_up ) > t_enter;
 }
 
 struct ClosestRanked { float depth; uint32_t rank; uint32_t tri; };
@@ -563,16 +564,17 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
     return ok;
 }
 
-// Of the children of a node whose boxes the ray enters, the nearest stays in a register (`cur`) -- or, when it is a leaf, goes straight into `leaf`: a lane that has
-// a leaf in hand HOLDS it -- and the others wait on the lane's stack, farthest first. The stack's first entries are an LDS column, the rest -- which a ray almost
-// never reaches: the column covers the depths rays actually see, the bound is the tree's worst case -- a few words of HBM per lane (fast_push / fast_pop).
+// A lane's traversal state is its stack and ONE register, `hand`: DEV_CHILD_EMPTY = nothing in hand; a node index = the node it descends into next; a leaf word =
+// the leaf whose triangles it is testing. Of the children of a node whose boxes the ray enters, the nearest goes into `hand` (so a descent step does not wait for an
+// LDS write + read of its own; a lane that has a leaf in hand HOLDS it) and the others wait on the lane's stack, farthest first. The stack's first entries are an
+// LDS column, the rest -- which a ray almost never reaches: the column covers the depths rays actually see, the bound is the tree's worst case -- a few words of HBM
+// per lane (fast_push / fast_pop). A ray starts with the root (node 0) in hand and an empty stack.
 // Each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and some lane can still descend) the descending lanes
 // take a node step, otherwise the holders test one triangle each. (16/16 is the classic "while-while" loop: descend until every lane holds a leaf.) The vote
 // trades a fuller node step against an emptier triangle step.
-// The traversal is resumable (stack in LDS / HBM; top, held leaf, closest hit in registers): it returns as soon as the
-// number of lanes still traversing has dropped to `exit_active`, so the render loop can shade the finished lanes and hand
-// them their next ray (exit_active = 0: run every lane's ray to the end). `traversing` is cleared for lanes whose traversal
-// completed. What a lane computes, and in which order, does not depend on the votes.
+// The traversal is resumable (stack in LDS / HBM; top, hand, closest hit in registers): it returns as soon as the number of lanes still traversing has dropped to
+// `exit_active`, so the render loop can shade the finished lanes and hand them their next ray (exit_active = 0: run every lane's ray to the end). A lane is done
+// when it has nothing in hand and its stack is empty (fast_traversing). What a lane computes, and in which order, does not depend on the votes.
 #ifndef TERRA_FAST_LEAF_16THS
 #define TERRA_FAST_LEAF_16THS 8
 #endif
@@ -581,6 +583,8 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
 #endif
 // (the test "is this entry in the LDS column" compares the entry's 32-bit LDS address with ONE wave-uniform limit: entry e of thread t sits at column base + e * 1024 + t * 4,
 //  and t * 4 < 1024, so address < base + cap * 1024 exactly when e < cap; the HBM index is computed on the cold side only)
+// (Entries that carry their box's entry distance, so that one the closest hit has overtaken is dropped when it comes off the stack, were measured: 8 % fewer node
+//  steps on the hall, 5 % on the sphere scene, and no time gained -- the second word and the pop loop cost what they save. profiles/r04_measurements/ab_fast_tree_knobs.log)
 TD void fast_push ( const Tracer& T, int*& top, uint32_t v ) {
     const uint32_t a = ( uint32_t ) ( uintptr_t ) top;
     // (bounds-checking builds: an entry beyond what the host planned -- LDS column + HBM part, the positive control's shrink taken off the column -- is refused and counted)
@@ -608,28 +612,26 @@ TD void order_pair ( uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb ) {
     const uint32_t k0 = swap ? kb : ka, k1 = swap ? ka : kb, c0 = swap ? cb : ca, c1 = swap ? ca : cb;
     ka = k0; kb = k1; ca = c0; cb = c1;
 }
+#define TERRA_FAST_ROOT_IN_HAND 0u
+TD bool fast_holds_leaf ( uint32_t hand ) { return ( int ) hand < -1; }          // (DEV_CHILD_EMPTY is -1; no leaf word is: a leaf has at most 4 triangles, so bits 29-30 of its count field are clear)
+TD bool fast_traversing ( const Tracer& T, uint32_t hand, const int* top ) { return ( hand != DEV_CHILD_EMPTY ) | ( top != T.stack ); }
 template <int COUNT>
-TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& leaf, bool& traversing, int exit_active, Counters& c, bool checked = false ) {
+TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& hand, int exit_active, Counters& c, bool checked = false ) {
     const FastRay f = fast_ray ( ray, T.sc.fast_inv_scale );
     const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes_h );
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
-    // `cur`: the node a lane descends into next stays in a register (the nearest child entered); only the others
-    // go through the stack, so a descent step does not wait for an LDS write + read of its own
-    uint32_t cur = DEV_CHILD_EMPTY;
     for ( ;; ) {
-        const bool holder = traversing && leaf != 0;
-        const bool can = traversing && leaf == 0 && ( cur != DEV_CHILD_EMPTY || top != T.stack );
-        const int n_can = __popcll ( __builtin_amdgcn_ballot_w64 ( can ) ), n_hold = __popcll ( __builtin_amdgcn_ballot_w64 ( holder ) );
-        traversing = can || holder;                                  // a lane with nothing in hand and an empty stack is done
+        // (the votes are taken on plain compares, whose results ARE wave masks; a vote on a combined bool costs a select + a compare to rebuild the mask)
+        const uint64_t m_hold = __builtin_amdgcn_ballot_w64 ( ( int ) hand < -1 ), m_node = __builtin_amdgcn_ballot_w64 ( ( int ) hand >= 0 ), m_stack = __builtin_amdgcn_ballot_w64 ( top != T.stack );
+        const int n_can = __popcll ( m_node | ( m_stack & ~m_hold ) ), n_hold = __popcll ( m_hold );
         if ( n_can + n_hold <= exit_active ) break;
         if ( n_can != 0 && n_hold * 16 < ( n_can + n_hold ) * TERRA_FAST_LEAF_16THS ) {
-            if ( can ) {
+            if ( ( ( int ) hand >= 0 ) | ( ( hand == DEV_CHILD_EMPTY ) & ( top != T.stack ) ) ) {
                 PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
-                uint32_t w = cur;
-                if ( w == DEV_CHILD_EMPTY ) w = fast_pop ( T, top );
-                cur = DEV_CHILD_EMPTY;
-                if ( w & DEV_CHILD_LEAF ) leaf = w;                  // (a leaf that waited on the stack)
-                else {
+                uint32_t w = hand;
+                if ( ( int ) w < 0 ) w = fast_pop ( T, top );
+                hand = w;                                            // (a leaf that waited on the stack stays in hand)
+                if ( ( int ) w >= 0 ) {
                     const uint32_t off = w << 6;
                     const uint4 q0 = *reinterpret_cast<const uint4*> ( nodes + off ), q1 = *reinterpret_cast<const uint4*> ( nodes + ( off + 16u ) ),
                                 q2 = *reinterpret_cast<const uint4*> ( nodes + ( off + 32u ) ), ch = *reinterpret_cast<const uint4*> ( nodes + ( off + 48u ) );      // {x0 y0 z0 x1} {y1 z1 x2 y2} {z2 x3 y3 z3} {children}
@@ -637,11 +639,12 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
+                    const float limit_up = __uint_as_float ( __float_as_uint ( best.depth ) + 1u );      // depth >= 0: the next float up (FLT_MAX -> inf)
                     float te0, te1, te2, te3;
-                    const bool hit0 = slab_half ( q0.x, q0.y, q0.z, f, te0 ) && te0 <= best.depth;
-                    const bool hit1 = slab_half ( q0.w, q1.x, q1.y, f, te1 ) && te1 <= best.depth;
-                    const bool hit2 = slab_half ( q1.z, q1.w, q2.x, f, te2 ) && te2 <= best.depth;
-                    const bool hit3 = slab_half ( q2.y, q2.z, q2.w, f, te3 ) && te3 <= best.depth;
+                    const bool hit0 = slab_half ( q0.x, q0.y, q0.z, f, limit_up, te0 );
+                    const bool hit1 = slab_half ( q0.w, q1.x, q1.y, f, limit_up, te1 );
+                    const bool hit2 = slab_half ( q1.z, q1.w, q2.x, f, limit_up, te2 );
+                    const bool hit3 = slab_half ( q2.y, q2.z, q2.w, f, limit_up, te3 );
                     // nearest first: the entry distances (>= 0, so their bit patterns order like the floats) sorted with their child words; a box not entered sorts last
                     uint32_t k0 = hit0 ? __float_as_uint ( te0 ) : 0xffffffffu, k1 = hit1 ? __float_as_uint ( te1 ) : 0xffffffffu, k2 = hit2 ? __float_as_uint ( te2 ) : 0xffffffffu, k3 = hit3 ? __float_as_uint ( te3 ) : 0xffffffffu;
                     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
@@ -650,19 +653,21 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
 #else               // (A/B) only the nearest is found; the others go on the stack in slot order
                     order_pair ( k0, c0, k1, c1 ); order_pair ( k0, c0, k2, c2 ); order_pair ( k0, c0, k3, c3 );
 #endif
-                    if ( k3 != 0xffffffffu ) fast_push ( T, top, c3 );          // the farthest goes in first, so the nearer ones come off first
+                    // the farthest goes in first, so the nearer ones come off first. (Branch-free pushes -- every child word stored at the top, the top moved only for the
+                    // entered ones -- measured no faster on the hall and 2 % slower on the sphere scene: profiles/r04_measurements/ab_fast_tree_knobs.log)
+                    if ( k3 != 0xffffffffu ) fast_push ( T, top, c3 );
                     if ( k2 != 0xffffffffu ) fast_push ( T, top, c2 );
                     if ( k1 != 0xffffffffu ) fast_push ( T, top, c1 );
 #if TERRA_PHASE_STATS
                     if ( k1 != 0xffffffffu ) { const int dpt = ( int ) ( top - T.stack ) / TERRA_COL; ++c.ps[kPsCamLanes]; c.ps[kPsShadeIter] += dpt >= 4; c.ps[kPsRayLanes] += dpt >= 6; c.ps[kPsCamIter] += dpt >= 8; c.ps[kPsDrainIter] += dpt >= 12; c.ps[kPsShadeLanes] += dpt >= 16; }
 #endif
-                    if ( k0 != 0xffffffffu ) { if ( c0 & DEV_CHILD_LEAF ) leaf = c0; else cur = c0; }
+                    hand = k0 != 0xffffffffu ? c0 : DEV_CHILD_EMPTY;
                 }
             }
-        } else if ( holder ) {
+        } else if ( ( int ) hand < -1 ) {
             PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
-            const uint32_t ti = leaf & 0x07ffffffu;
-            leaf = ( leaf & 0x78000000u ) ? leaf + 1u - 0x08000000u : 0u;        // next triangle of the leaf, one fewer to go; 0 = nothing in hand
+            const uint32_t ti = hand & 0x07ffffffu;
+            hand = ( hand & 0x78000000u ) ? hand + 1u - 0x08000000u : DEV_CHILD_EMPTY;        // next triangle of the leaf, one fewer to go
             const float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];          // three loads: every wave-level load instruction costs the texture addresser the same ~21 cycles
             const V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
             const float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
@@ -678,7 +683,6 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             }
         }
     }
-    if ( cur != DEV_CHILD_EMPTY ) fast_push ( T, top, cur );      // leaving with a node in hand: it waits on the stack
 }
 
 // REACH = false: the kernels launched for scenes inside the coordinate range (template MODE 2) carry none of the replay code; MODE 3 = the same loops with it
@@ -691,9 +695,8 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
     for ( int pass = 0; pass < 2; ++pass ) {
         best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
         int* top = T.stack;
-        *top = 0; top += TERRA_COL;
-        bool traversing = true; uint32_t leaf = 0;
-        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, leaf, traversing, 0, c, REACH && pass == 1 );
+        uint32_t hand = TERRA_FAST_ROOT_IN_HAND;
+        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, hand, 0, c, REACH && pass == 1 );
         if ( !REACH || pass == 1 || !T.sc.reach || best.tri == 0xffffffffu || reference_reaches ( T, best.tri, r ) ) break;
     }
     return best;
