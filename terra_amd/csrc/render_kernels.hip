@@ -232,9 +232,9 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
-struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, hand; int top; bool traversing, regular; };     // hand: MODE >= 2, what the lane holds between calls (trace_device.h traverse_fast_resume)     // regular: MODE 0 / 1 the ray's slab variant; MODE 2 (which has no use for that) "second, checked pass" of the reachability mode     // top: entries on the lane's stack (its leaf list is always empty between calls)
+struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, hand, held; int top; bool traversing, regular; };     // hand: MODE >= 2, what the lane holds between calls (trace_device.h traverse_fast_resume)     // regular: MODE 0 / 1 the ray's slab variant; MODE 2 (which has no use for that) "second, checked pass" of the reachability mode     // top: entries on the lane's stack (its leaf list is always empty between calls)
 TD LaneTraversal lane_traversal_idle ( const Tracer& T, const Ray& any_ray ) {
-    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.hand = DEV_CHILD_EMPTY; t.top = 0; t.traversing = false; t.regular = true;
+    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.hand = DEV_CHILD_EMPTY; t.held = 0u; t.top = 0; t.traversing = false; t.regular = true;
     return t;
 }
 // puts `ray` in flight: the origin offset terra_scene_raycast applies (src/Terra.c:1629-1630), ray state, empty closest hit, root on the stack
@@ -245,7 +245,7 @@ TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t
     t.sel = slab_sel ( r );
     t.regular = ray_is_regular ( r );
     t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu;
-    if ( MODE >= 2 ) { t.hand = TERRA_FAST_ROOT_IN_HAND; t.top = 0; }      // the fast tree's traversal starts with the root in hand
+    if ( MODE >= 2 ) { t.hand = TERRA_FAST_ROOT_IN_HAND; t.held = 0u; t.top = 0; }      // the fast tree's traversal starts with the root in hand
     else { *T.stack = 0; t.top = 1; }
     t.traversing = true;
     if ( COUNT ) ++c.rays;
@@ -258,7 +258,7 @@ TD bool lane_traversal_recheck ( const Tracer& T, const Ray& ray, LaneTraversal&
     Ray r = ray; r.o = r.o + r.d * 0.001f;
     if ( reference_reaches ( T, t.best.tri, r ) ) return false;
     t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu;
-    t.hand = TERRA_FAST_ROOT_IN_HAND; t.top = 0;
+    t.hand = TERRA_FAST_ROOT_IN_HAND; t.held = 0u; t.top = 0;
     t.traversing = true; t.regular = false;
     return true;
 }
@@ -274,8 +274,8 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
     int* sp = T.stack + t.top * TERRA_COL;
     if constexpr ( MODE >= 2 ) {
         ClosestRanked b2; b2.depth = t.best.depth; b2.rank = t.rank; b2.tri = t.best.tri;
-        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.hand, exit_active, c, MODE == 3 && T.sc.reach && !t.regular );      // (a ray with a zero direction component starts in the checked pass: harmless)
-        t.traversing = fast_traversing ( T, t.hand, sp );
+        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.hand, t.held, exit_active, c, MODE == 3 && T.sc.reach && !t.regular );      // (a ray with a zero direction component starts in the checked pass: harmless)
+        t.traversing = fast_traversing ( T, t.hand, t.held, sp );
         t.best.depth = b2.depth; t.best.tri = b2.tri; t.rank = b2.rank;
     } else {
         if ( __all ( !t.traversing || t.regular ) ) traverse_resume<COUNT, MODE, true> ( T, r, t.sel, t.st, o_perm, t.best, sp, t.traversing, exit_active, c );

@@ -564,19 +564,23 @@ TD bool reference_reaches ( const Tracer& T, uint32_t ti, const Ray& ray ) {
     return ok;
 }
 
-// A lane's traversal state is its stack and ONE register, `hand`: DEV_CHILD_EMPTY = nothing in hand; a node index = the node it descends into next; a leaf word =
-// the leaf whose triangles it is testing. Of the children of a node whose boxes the ray enters, the nearest goes into `hand` (so a descent step does not wait for an
-// LDS write + read of its own; a lane that has a leaf in hand HOLDS it) and the others wait on the lane's stack, farthest first. The stack's first entries are an
-// LDS column, the rest -- which a ray almost never reaches: the column covers the depths rays actually see, the bound is the tree's worst case -- a few words of HBM
-// per lane (fast_push / fast_pop). A ray starts with the root (node 0) in hand and an empty stack.
-// Each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and some lane can still descend) the descending lanes
-// take a node step, otherwise the holders test one triangle each. (16/16 is the classic "while-while" loop: descend until every lane holds a leaf.) The vote
-// trades a fuller node step against an emptier triangle step.
-// The traversal is resumable (stack in LDS / HBM; top, hand, closest hit in registers): it returns as soon as the number of lanes still traversing has dropped to
+// A lane's traversal state is its stack and TWO registers. `held`: the leaf whose triangles it is testing (0 = none). `hand`: DEV_CHILD_EMPTY = nothing; a node
+// index = the node it descends into next; a leaf word = the next leaf, waiting for `held` to be free. Of the children of a node whose boxes the ray enters, the
+// nearest goes into `hand` (so a descent step does not wait for an LDS write + read of its own) -- or straight into `held` when it is a leaf and `held` is free --
+// and the others wait on the lane's stack, farthest first. The stack's first entries are an LDS column, the rest -- which a ray almost never reaches: the column
+// covers the depths rays actually see, the bound is the tree's worst case -- a few words of HBM per lane (fast_push / fast_pop). A ray starts with the root
+// (node 0) in hand and an empty stack.
+// Each iteration the wave votes: while fewer than TERRA_FAST_LEAF_16THS / 16 of its busy lanes hold a leaf (and some lane can still descend) the lanes that can
+// descend take a node step, otherwise the holders test one triangle each. A lane that holds a leaf does NOT wait for the triangle step: it goes on descending
+// towards its next leaf (speculatively: had its held leaf been tested first, the closer hit might have culled some of those nodes) and only stops when that one is
+// in hand too. Without this, node steps ran 61 % full and triangle steps 40 % (hall); the few extra node visits cost less than the fuller steps save
+// (profiles/r04_measurements/ab_fast_tree_knobs.log). (16/16 would be the classic "while-while" loop: descend until every lane holds a leaf.)
+// The traversal is resumable (stack in LDS / HBM; top, hand, held, closest hit in registers): it returns as soon as the number of busy lanes has dropped to
 // `exit_active`, so the render loop can shade the finished lanes and hand them their next ray (exit_active = 0: run every lane's ray to the end). A lane is done
-// when it has nothing in hand and its stack is empty (fast_traversing). What a lane computes, and in which order, does not depend on the votes.
+// when it holds nothing and its stack is empty (fast_traversing). WHICH nodes a lane visits depends on the votes (on when its held leaf is tested), the closest hit
+// it returns does not: that is the minimum over (depth, reference visit rank) of the triangles the ray hits, and no box that holds it is ever culled.
 #ifndef TERRA_FAST_LEAF_16THS
-#define TERRA_FAST_LEAF_16THS 8
+#define TERRA_FAST_LEAF_16THS 12
 #endif
 #ifndef TERRA_FAST_SORT            // 1: the entered children of a node are visited nearest first (sorting network); 0: nearest first, the rest in slot order (A/B)
 #define TERRA_FAST_SORT 1
@@ -614,23 +618,24 @@ TD void order_pair ( uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb ) {
 }
 #define TERRA_FAST_ROOT_IN_HAND 0u
 TD bool fast_holds_leaf ( uint32_t hand ) { return ( int ) hand < -1; }          // (DEV_CHILD_EMPTY is -1; no leaf word is: a leaf has at most 4 triangles, so bits 29-30 of its count field are clear)
-TD bool fast_traversing ( const Tracer& T, uint32_t hand, const int* top ) { return ( hand != DEV_CHILD_EMPTY ) | ( top != T.stack ); }
+TD bool fast_traversing ( const Tracer& T, uint32_t hand, uint32_t held, const int* top ) { return ( hand != DEV_CHILD_EMPTY ) | ( top != T.stack ) | ( held != 0u ); }
 template <int COUNT>
-TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& hand, int exit_active, Counters& c, bool checked = false ) {
+TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& hand, uint32_t& held, int exit_active, Counters& c, bool checked = false ) {
     const FastRay f = fast_ray ( ray, T.sc.fast_inv_scale );
     const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes_h );
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
     for ( ;; ) {
         // (the votes are taken on plain compares, whose results ARE wave masks; a vote on a combined bool costs a select + a compare to rebuild the mask)
-        const uint64_t m_hold = __builtin_amdgcn_ballot_w64 ( ( int ) hand < -1 ), m_node = __builtin_amdgcn_ballot_w64 ( ( int ) hand >= 0 ), m_stack = __builtin_amdgcn_ballot_w64 ( top != T.stack );
-        const int n_can = __popcll ( m_node | ( m_stack & ~m_hold ) ), n_hold = __popcll ( m_hold );
-        if ( n_can + n_hold <= exit_active ) break;
-        if ( n_can != 0 && n_hold * 16 < ( n_can + n_hold ) * TERRA_FAST_LEAF_16THS ) {
+        // a lane TESTS the leaf in `held` and may meanwhile descend on towards its next one (which then waits in hand): busy = can descend or holds
+        const uint64_t m_hold = __builtin_amdgcn_ballot_w64 ( held != 0u ), m_can = __builtin_amdgcn_ballot_w64 ( ( int ) hand >= 0 ) | ( __builtin_amdgcn_ballot_w64 ( hand == DEV_CHILD_EMPTY ) & __builtin_amdgcn_ballot_w64 ( top != T.stack ) );
+        const int n_can = __popcll ( m_can ), n_hold = __popcll ( m_hold ), n_busy = __popcll ( m_can | m_hold );
+        if ( n_busy <= exit_active ) break;
+        if ( n_can != 0 && n_hold * 16 < n_busy * TERRA_FAST_LEAF_16THS ) {
             if ( ( ( int ) hand >= 0 ) | ( ( hand == DEV_CHILD_EMPTY ) & ( top != T.stack ) ) ) {
                 PS_WAVE ( c, kPsNodeIter ); PS_LANE ( c, kPsNodeLanes );
                 uint32_t w = hand;
                 if ( ( int ) w < 0 ) w = fast_pop ( T, top );
-                hand = w;                                            // (a leaf that waited on the stack stays in hand)
+                uint32_t nw = w;                                     // (a leaf that waited on the stack stays in hand)
                 if ( ( int ) w >= 0 ) {
                     const uint32_t off = w << 6;
                     const uint4 q0 = *reinterpret_cast<const uint4*> ( nodes + off ), q1 = *reinterpret_cast<const uint4*> ( nodes + ( off + 16u ) ),
@@ -661,13 +666,16 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
 #if TERRA_PHASE_STATS
                     if ( k1 != 0xffffffffu ) { const int dpt = ( int ) ( top - T.stack ) / TERRA_COL; ++c.ps[kPsCamLanes]; c.ps[kPsShadeIter] += dpt >= 4; c.ps[kPsRayLanes] += dpt >= 6; c.ps[kPsCamIter] += dpt >= 8; c.ps[kPsDrainIter] += dpt >= 12; c.ps[kPsShadeLanes] += dpt >= 16; }
 #endif
-                    hand = k0 != 0xffffffffu ? c0 : DEV_CHILD_EMPTY;
+                    nw = k0 != 0xffffffffu ? c0 : DEV_CHILD_EMPTY;
                 }
+                { const bool take = ( ( int ) nw < -1 ) & ( held == 0u ); held = take ? nw : held; nw = take ? DEV_CHILD_EMPTY : nw; }      // a leaf goes to the testing slot if that is free
+                hand = nw;
             }
-        } else if ( ( int ) hand < -1 ) {
+        } else if ( held != 0u ) {
             PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
-            const uint32_t ti = hand & 0x07ffffffu;
-            hand = ( hand & 0x78000000u ) ? hand + 1u - 0x08000000u : DEV_CHILD_EMPTY;        // next triangle of the leaf, one fewer to go
+            const uint32_t ti = held & 0x07ffffffu;
+            held = ( held & 0x78000000u ) ? held + 1u - 0x08000000u : 0u;        // next triangle of the leaf, one fewer to go
+            if ( ( held == 0u ) & ( ( int ) hand < -1 ) ) { held = hand; hand = DEV_CHILD_EMPTY; }      // the leaf that waited in hand moves up
             const float4 a = tris[3 * ti], b = tris[3 * ti + 1], cc = tris[3 * ti + 2];          // three loads: every wave-level load instruction costs the texture addresser the same ~21 cycles
             const V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
             const float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
@@ -695,8 +703,8 @@ TD ClosestRanked bvh_traverse_fast ( const Tracer& T, const Ray& r, const RaySta
     for ( int pass = 0; pass < 2; ++pass ) {
         best.depth = FLT_MAX; best.rank = 0xffffffffu; best.tri = 0xffffffffu;
         int* top = T.stack;
-        uint32_t hand = TERRA_FAST_ROOT_IN_HAND;
-        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, hand, 0, c, REACH && pass == 1 );
+        uint32_t hand = TERRA_FAST_ROOT_IN_HAND, held = 0u;
+        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, hand, held, 0, c, REACH && pass == 1 );
         if ( !REACH || pass == 1 || !T.sc.reach || best.tri == 0xffffffffu || reference_reaches ( T, best.tri, r ) ) break;
     }
     return best;
