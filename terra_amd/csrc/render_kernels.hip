@@ -232,9 +232,9 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
                                  : TERRA_DECOUPLED ( I, M ) ? TERRA_WAVES_DECOUPLED : ( ( K ) == 1 ? TERRA_WAVES_SIMPLE : TERRA_WAVES_GENERIC ) )
 // ---- pieces shared by the decoupled loops of the kernel below -----------------------------------------
 // Per-lane traversal state that survives leaving the resumable traversal (the stack column and the leaf list are in LDS).
-struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, hand, held; int top; bool traversing, regular; };     // hand: MODE >= 2, what the lane holds between calls (trace_device.h traverse_fast_resume)     // regular: MODE 0 / 1 the ray's slab variant; MODE 2 (which has no use for that) "second, checked pass" of the reachability mode     // top: entries on the lane's stack (its leaf list is always empty between calls)
+struct LaneTraversal { RayState st; SlabSel sel; Closest best; uint32_t rank, hand, held; int top; bool traversing, regular, anyhit; };     // anyhit: a light-sample ray that knows its triangle (trace_device.h fast_expect)     // hand: MODE >= 2, what the lane holds between calls (trace_device.h traverse_fast_resume)     // regular: MODE 0 / 1 the ray's slab variant; MODE 2 (which has no use for that) "second, checked pass" of the reachability mode     // top: entries on the lane's stack (its leaf list is always empty between calls)
 TD LaneTraversal lane_traversal_idle ( const Tracer& T, const Ray& any_ray ) {
-    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.hand = DEV_CHILD_EMPTY; t.held = 0u; t.top = 0; t.traversing = false; t.regular = true;
+    LaneTraversal t; t.st = ray_state_init ( any_ray ); t.sel = slab_sel ( any_ray ); t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu; t.hand = DEV_CHILD_EMPTY; t.held = 0u; t.top = 0; t.anyhit = false; t.traversing = false; t.regular = true;
     return t;
 }
 // puts `ray` in flight: the origin offset terra_scene_raycast applies (src/Terra.c:1629-1630), ray state, empty closest hit, root on the stack
@@ -245,10 +245,22 @@ TD void lane_traversal_start ( const Tracer& T, const Ray& ray, LaneTraversal& t
     t.sel = slab_sel ( r );
     t.regular = ray_is_regular ( r );
     t.best.depth = FLT_MAX; t.best.tri = 0xffffffffu; t.rank = 0xffffffffu;
-    if ( MODE >= 2 ) { t.hand = TERRA_FAST_ROOT_IN_HAND; t.held = 0u; t.top = 0; }      // the fast tree's traversal starts with the root in hand
+    if ( MODE >= 2 ) { t.hand = TERRA_FAST_ROOT_IN_HAND; t.held = 0u; t.top = 0; t.anyhit = false; }      // the fast tree's traversal starts with the root in hand
     else { *T.stack = 0; t.top = 1; }
     t.traversing = true;
     if ( COUNT ) ++c.rays;
+}
+// the ray just started is a light-sample ray towards triangle `expected` (soup index): trace_device.h fast_expect. (A ray that misses its triangle stays an ordinary ray.)
+template <int COUNT, int MODE>
+TD void lane_traversal_expect ( const Tracer& T, const Ray& ray, LaneTraversal& t, uint32_t expected ) {
+    if constexpr ( TERRA_SHADOW_ANYHIT && MODE == 2 && COUNT == 0 ) {
+        Ray r = ray; r.o = r.o + r.d * 0.001f;
+        const V3 o_perm = v3 ( pick ( r.o, t.st.ix ), pick ( r.o, t.st.iy ), pick ( r.o, t.st.iz ) );
+        ClosestRanked b2; b2.depth = t.best.depth; b2.rank = t.rank; b2.tri = t.best.tri;
+        t.anyhit = fast_expect ( T, t.st, o_perm, expected, b2 );
+        t.best.depth = b2.depth; t.best.tri = b2.tri; t.rank = b2.rank;
+        if ( !t.anyhit ) { t.hand = DEV_CHILD_EMPTY; t.traversing = false; }      // the ray misses its triangle: whatever it hits instead, the answer is "not the expected one" (best.tri: none)
+    }
 }
 // DevScene::reach (scenes outside the coordinate range of the containment proof, MODE 2): a returned closest hit stands if the reference traversal would have
 // reached it; if not -- very rare -- the same ray goes back in flight with every candidate checked (trace_device.h bvh_traverse_fast). True = the lane is traversing again.
@@ -274,7 +286,7 @@ TD bool lane_traversal_run ( const Tracer& T, const Ray& ray, LaneTraversal& t, 
     int* sp = T.stack + t.top * TERRA_COL;
     if constexpr ( MODE >= 2 ) {
         ClosestRanked b2; b2.depth = t.best.depth; b2.rank = t.rank; b2.tri = t.best.tri;
-        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.hand, t.held, exit_active, c, MODE == 3 && T.sc.reach && !t.regular );      // (a ray with a zero direction component starts in the checked pass: harmless)
+        traverse_fast_resume<COUNT> ( T, r, t.st, o_perm, b2, sp, t.hand, t.held, exit_active, c, MODE == 3 && T.sc.reach && !t.regular, TERRA_SHADOW_ANYHIT && MODE == 2 && COUNT == 0 && t.anyhit );      // (a ray with a zero direction component starts in the checked pass: harmless)
         t.traversing = fast_traversing ( T, t.hand, t.held, sp );
         t.best.depth = b2.depth; t.best.tri = b2.tri; t.rank = b2.rank;
     } else {
@@ -525,7 +537,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                 bool start = false;
                 V3 ro = v3 ( 0, 0, 0 ), rd = v3 ( 0, 0, 1 );
                 if ( have_ray && shadow ) {                      // the shadow ray came back
-                    const uint32_t tri_s = hit_soup_index<MODE> ( T, lt.best.tri );
+                    const uint32_t tri_s = ( TERRA_SHADOW_ANYHIT && MODE == 2 && COUNT == 0 && lt.best.tri == TERRA_TRI_EXPECTED ) ? pend.expected : hit_soup_index<MODE> ( T, lt.best.tri );
                     if ( tri_s != 0xffffffffu ) {                   // (its hit counts as a surface init, as in the coupled form)
                         if ( COUNT ) ++c.hits;
                         if ( COUNT == 2 ) { const float4 t0 = reinterpret_cast<const float4*> ( T.sc.tris ) [3 * tri_s]; c.attr_fetches += T.sc.mats[__float_as_uint ( t0.w )].attributes_count + 1; }
@@ -558,7 +570,10 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                         Lo = v3 ( 0, 0, 0 ); throughput = v3 ( 1, 1, 1 ); bounce = 0; ++jb.s; start = true;
                     }
                 }
-                if ( start ) { ray = make_ray ( ro, rd ); lane_traversal_start<COUNT, MODE> ( T, ray, lt, c ); have_ray = true; }
+                if ( start ) {
+                    ray = make_ray ( ro, rd ); lane_traversal_start<COUNT, MODE> ( T, ray, lt, c ); have_ray = true;
+                    if ( shadow ) lane_traversal_expect<COUNT, MODE> ( T, ray, lt, pend.expected );
+                }
             }
             if ( !lane_traversal_run<COUNT, MODE> ( T, ray, lt, c ) && __all ( done ) ) break;      // nobody traversing and no job left
         }
@@ -666,7 +681,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     pd = path_draw<COUNT> ( T.sc.sincos24, rs.b, c );
                     end = !path_continue<KINDS> ( sf, wo, throughput, bounce, p.bounces, pd, wi );
                     if ( !end ) { ro = h.point + sf.normal * 0.0001f; rd = wi; }
-                    const uint32_t tri = scene_raycast_triangle<COUNT, MODE> ( T, shadow_ray, c );
+                    const uint32_t tri = scene_raycast_triangle<COUNT, MODE> ( T, shadow_ray, c, pend.expected );
                     lo_add ( tri == pend.expected ? pend.vis : pend.hid );
                 } else if constexpr ( TERRA_COUPLED_MIS_SPLIT && INTEGRATOR == 2 && ( KINDS & ( TERRA_KIND_TEX | TERRA_KIND_SAMPLER ) ) == 0 ) {
                     // Direct + MIS split the same way at its two rays (mis_prepare / mis_finish_b, src/Terra.c:1428-1587): A, the ray to the light sample, only has to
@@ -676,7 +691,7 @@ __global__ __launch_bounds__ ( 256, TERRA_WAVES_FOR ( INTEGRATOR, KINDS, MODE ) 
                     const V3 next_o = h.point + sf.normal * 0.0001f;          // surface_ray ( sf, h.point, direction, 1.f ) for B and for the continuation alike
                     end = !path_continue<COUNT, KINDS> ( T.sc, sf, wo, throughput, bounce, p.bounces, rs.b, c, wi, sp );
                     if ( !end ) { ro = next_o; rd = wi; }
-                    const uint32_t tri_a = scene_raycast_triangle<COUNT, MODE> ( T, ray_a, c );
+                    const uint32_t tri_a = scene_raycast_triangle<COUNT, MODE> ( T, ray_a, c, pend.expected );
                     const V3 lo_a = tri_a == pend.expected ? pend.a_vis : pend.a_hid;
                     Surface lsf;
                     const RaycastResult hb = scene_raycast<COUNT, MODE, KINDS> ( T, make_ray ( next_o, b_d ), lsf, c );

@@ -885,6 +885,7 @@ static int upload_scene ( Scene* s ) {
                 }
             }
         }
+        for ( size_t k = 0; k < ntri; ++k ) tris[k].pad = rank[k];      // the soup carries the ranks too: a light-sample ray tests its triangle before it traverses (trace_device.h fast_expect)
         s->fast_on_device = s->tree_builder == 1 && ntri > 64 && terra_amd_device_count() > 0;
         if ( s->fast_on_device ) {
             // built after the upload, from the soup already in HBM; the host only supplies the reference visit ranks

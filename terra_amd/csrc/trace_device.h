@@ -620,7 +620,7 @@ TD void order_pair ( uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb ) {
 TD bool fast_holds_leaf ( uint32_t hand ) { return ( int ) hand < -1; }          // (DEV_CHILD_EMPTY is -1; no leaf word is: a leaf has at most 4 triangles, so bits 29-30 of its count field are clear)
 TD bool fast_traversing ( const Tracer& T, uint32_t hand, uint32_t held, const int* top ) { return ( hand != DEV_CHILD_EMPTY ) | ( top != T.stack ) | ( held != 0u ); }
 template <int COUNT>
-TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& hand, uint32_t& held, int exit_active, Counters& c, bool checked = false ) {
+TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& hand, uint32_t& held, int exit_active, Counters& c, bool checked = false, bool anyhit = false ) {
     const FastRay f = fast_ray ( ray, T.sc.fast_inv_scale );
     const char* nodes = reinterpret_cast<const char*> ( T.sc.fast_nodes_h );
     const float4* tris = reinterpret_cast<const float4*> ( T.sc.fast_tris );
@@ -687,10 +687,36 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
             if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) {
                 if ( depth < best.depth || ( depth == best.depth && rank < best.rank ) ) {
                     if ( !checked || reference_reaches ( T, ti, ray ) ) { best.depth = depth; best.rank = rank; best.tri = ti; }      // (checked: DevScene::reach, second pass)
+                    // a shadow ray that knows the triangle it expects (fast_expect) only asks whether ANY triangle comes first: this one does, the lane is done
+                    if ( anyhit ) { top = T.stack; hand = DEV_CHILD_EMPTY; held = 0u; }
                 }
             }
         }
     }
+}
+
+// A ray of which only "is triangle E the closest hit" matters -- the light-sample ray of the Direct and MIS integrators (src/Terra.c:1349-1426: the sample counts when
+// the ray's closest hit is the sampled light triangle) -- need not search for its closest hit. E is tested first, with the arithmetic the traversal would use on it; if
+// the ray misses E the answer is no, whatever else it hits (false: the caller traces the ray the ordinary way, for the hit count). Otherwise the traversal starts from
+// the closest hit (depth of E, rank of E): every box beyond E is culled from the first node on, and the first triangle that beats E -- nearer, or as near with a smaller
+// reference visit rank: exactly the triangles the reference's traversal would have preferred -- ends it (traverse_fast_resume `anyhit`). best.tri stays
+// TERRA_TRI_EXPECTED if none does. Scenes inside the coordinate range only (MODE 2: what the reference reaches needs no replay), kernels without work counters only
+// (the attribute-fetch counter is defined by the CLOSEST hit's material). DevTri::pad of the soup holds the rank when the scene has a fast tree.
+#define TERRA_TRI_EXPECTED 0xfffffffeu
+#ifndef TERRA_SHADOW_ANYHIT
+#define TERRA_SHADOW_ANYHIT 1
+#endif
+TD bool fast_expect ( const Tracer& T, const RayState& st, V3 o_perm, uint32_t expected_soup, ClosestRanked& best ) {
+    const float4* tris = reinterpret_cast<const float4*> ( T.sc.tris );
+    const float4 a = tris[3 * expected_soup], b = tris[3 * expected_soup + 1], cc = tris[3 * expected_soup + 2];
+    const V3 va = v3 ( a.x, a.y, a.z ), vb = v3 ( b.x, b.y, b.z ), vc = v3 ( cc.x, cc.y, cc.z );
+    const float pa[3] = { pick ( va, st.ix ), pick ( va, st.iy ), pick ( va, st.iz ) };
+    const float pb[3] = { pick ( vb, st.ix ), pick ( vb, st.iy ), pick ( vb, st.iz ) };
+    const float pc[3] = { pick ( vc, st.ix ), pick ( vc, st.iy ), pick ( vc, st.iz ) };
+    float depth;
+    if ( !watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) return false;
+    best.depth = depth; best.rank = __float_as_uint ( cc.w ); best.tri = TERRA_TRI_EXPECTED;
+    return true;
 }
 
 // REACH = false: the kernels launched for scenes inside the coordinate range (template MODE 2) carry none of the replay code; MODE 3 = the same loops with it
@@ -878,12 +904,23 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
 // terra_scene_raycast for a ray of which only "which triangle is hit first" matters (the shadow ray of the Direct integrator, src/Terra.c:1349-1426, on scenes whose
 // emissive attributes are constants): same traversal, same counts -- a hit is a surface initialisation in the reference -- without setting the surface up.
 // Returns the triangle's index in the soup (the index the light tables use), 0xffffffff for a miss.
+// `expected` (soup index): the only answer the caller distinguishes from the others; kernels without counters then take the shortcut of fast_expect on MODE 2
 template <int COUNT, int MODE>
-TD uint32_t scene_raycast_triangle ( const Tracer& T, const Ray& in, Counters& c ) {
+TD uint32_t scene_raycast_triangle ( const Tracer& T, const Ray& in, Counters& c, uint32_t expected = 0xffffffffu ) {
     Ray r = in;
     r.o = r.o + r.d * 0.001f;
     RayState st = ray_state_init ( r );
     if ( COUNT ) ++c.rays;
+    if constexpr ( TERRA_SHADOW_ANYHIT && MODE == 2 && COUNT == 0 ) {
+        if ( expected != 0xffffffffu ) {
+            const V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+            ClosestRanked best;
+            if ( !fast_expect ( T, st, o_perm, expected, best ) ) return 0xffffffffu;          // (not the expected triangle; without counters nothing else is asked)
+            int* top = T.stack; uint32_t hand = TERRA_FAST_ROOT_IN_HAND, held = 0u;
+            traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, hand, held, 0, c, false, true );
+            return best.tri == TERRA_TRI_EXPECTED ? expected : 0xffffffffu;
+        }
+    }
     uint32_t tri;
     if ( MODE >= 2 ) { const ClosestRanked b2 = bvh_traverse_fast<COUNT, MODE == 3> ( T, r, st, c ); tri = b2.tri; }
     else tri = bvh_traverse<COUNT, MODE> ( T, r, st, c ).tri;
