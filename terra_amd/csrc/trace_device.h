@@ -428,8 +428,9 @@ TD void node_step ( const Tracer& T, const Ray& r, const SlabSel& sel, int*& sp,
 }
 
 // triangle test of one entry of the lane's leaf list, in the order the leaves were met: strict "<" keeps the first of equal depths
-template <int COUNT, int MODE>
-TD void leaf_step ( const Tracer& T, const int* entry, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
+// (expected != none: the ray only asks whether its closest hit is triangle `expected` -- scene_raycast_triangle -- and `stop` is set by the first other triangle that comes first)
+template <int COUNT, int MODE, bool ANYHIT = false>
+TD void leaf_step ( const Tracer& T, const int* entry, const RayState& st, V3 o_perm, Closest& best, Counters& c, uint32_t expected = 0xffffffffu, bool* stop = nullptr ) {
     const float4* g_tris = reinterpret_cast<const float4*> ( T.sc.tris );
     const int kx = st.ix, ky = st.iy, kz = st.iz;
     PS_WAVE ( c, kPsLeafIter ); PS_LANE ( c, kPsLeafLanes );
@@ -450,11 +451,11 @@ TD void leaf_step ( const Tracer& T, const int* entry, const RayState& st, V3 o_
     }
     if ( COUNT ) ++c.tri_tests;
     float depth;
-    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; }
+    if ( watertight_permuted ( pa, pb, pc, o_perm, st, depth ) && depth < best.depth ) { best.depth = depth; best.tri = ti; if ( ANYHIT && ti != expected ) *stop = true; }
 }
 
-template <int COUNT, int MODE, bool FAST, bool FUSED = false>
-TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c ) {
+template <int COUNT, int MODE, bool FAST, bool FUSED = false, bool ANYHIT = false>
+TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o_perm, Closest& best, Counters& c, uint32_t expected = 0xffffffffu ) {
     const SlabSel sel = slab_sel ( r );
     int* sp = T.stack; int* lp = T.leaves;
     int* const lp_full = T.leaves + ( T.leaf_cap - 2 ) * TERRA_COL;       // a node adds at most two leaves
@@ -462,20 +463,25 @@ TD void traverse_loops ( const Tracer& T, const Ray& r, const RayState& st, V3 o
     for ( ;; ) {
         PS_WAVE ( c, kPsDrainIter );
         while ( sp != T.stack && lp <= lp_full ) node_step<COUNT, MODE, FAST, FUSED> ( T, r, sel, sp, lp, c );
+        if constexpr ( ANYHIT ) {
+            bool stop = false;
+            for ( const int* e = T.leaves; e != lp && !stop; e += TERRA_COL ) leaf_step<COUNT, MODE, true> ( T, e, st, o_perm, best, c, expected, &stop );
+            if ( stop ) sp = T.stack;                                  // another triangle comes first: nothing further can change the answer
+        } else
         for ( const int* e = T.leaves; e != lp; e += TERRA_COL ) leaf_step<COUNT, MODE> ( T, e, st, o_perm, best, c );
         lp = T.leaves;
         if ( sp == T.stack ) break;
     }
 }
 
+#ifndef TERRA_FUSED_SLAB
+#define TERRA_FUSED_SLAB 1
+#endif
 template <int COUNT, int MODE>
 TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Counters& c ) {
     Closest best; best.depth = FLT_MAX; best.tri = 0xffffffffu;
     V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
     // the slab variant is chosen per WAVE: one irregular ray sends its whole wave down the exact path
-#ifndef TERRA_FUSED_SLAB
-#define TERRA_FUSED_SLAB 1
-#endif
     if ( TERRA_FUSED_SLAB && MODE == 1 && T.fused && __all ( ray_is_tame ( r ) ) ) traverse_loops<COUNT, MODE, true, true> ( T, r, st, o_perm, best, c );
     else if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true> ( T, r, st, o_perm, best, c );
     else traverse_loops<COUNT, MODE, false> ( T, r, st, o_perm, best, c );
@@ -644,7 +650,7 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
-                    const float limit_up = __uint_as_float ( __float_as_uint ( best.depth ) + 1u );      // depth >= 0: the next float up (FLT_MAX -> inf)
+                    const float limit_up = __uint_as_float ( __float_as_uint ( best.depth + 0.f ) + 1u );      // the next float up (FLT_MAX -> inf); + 0.f: a hit at depth -0 counts as +0
                     float te0, te1, te2, te3;
                     const bool hit0 = slab_half ( q0.x, q0.y, q0.z, f, limit_up, te0 );
                     const bool hit1 = slab_half ( q0.w, q1.x, q1.y, f, limit_up, te1 );
@@ -906,20 +912,34 @@ TD RaycastResult scene_raycast ( const Tracer& T, const Ray& in, Surface& sf, Co
 // Returns the triangle's index in the soup (the index the light tables use), 0xffffffff for a miss.
 // `expected` (soup index): the only answer the caller distinguishes from the others; kernels without counters then take the shortcut of fast_expect on MODE 2
 template <int COUNT, int MODE>
-TD uint32_t scene_raycast_triangle ( const Tracer& T, const Ray& in, Counters& c, uint32_t expected = 0xffffffffu ) {
+TD uint32_t scene_raycast_triangle ( const Tracer& T, const Ray& in, Counters& c, uint32_t expected ) {
     Ray r = in;
     r.o = r.o + r.d * 0.001f;
     RayState st = ray_state_init ( r );
     if ( COUNT ) ++c.rays;
     if constexpr ( TERRA_SHADOW_ANYHIT && MODE == 2 && COUNT == 0 ) {
-        if ( expected != 0xffffffffu ) {
-            const V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
-            ClosestRanked best;
-            if ( !fast_expect ( T, st, o_perm, expected, best ) ) return 0xffffffffu;          // (not the expected triangle; without counters nothing else is asked)
-            int* top = T.stack; uint32_t hand = TERRA_FAST_ROOT_IN_HAND, held = 0u;
-            traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, hand, held, 0, c, false, true );
-            return best.tri == TERRA_TRI_EXPECTED ? expected : 0xffffffffu;
-        }
+        const V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+        ClosestRanked best;
+        if ( !fast_expect ( T, st, o_perm, expected, best ) ) return 0xffffffffu;          // (not the expected triangle; without counters nothing else is asked)
+        int* top = T.stack; uint32_t hand = TERRA_FAST_ROOT_IN_HAND, held = 0u;
+        traverse_fast_resume<COUNT> ( T, r, st, o_perm, best, top, hand, held, 0, c, false, true );
+        return best.tri == TERRA_TRI_EXPECTED ? expected : 0xffffffffu;
+    }
+    // LDS-resident scenes, every tree mode: the reference's traversal order is kept, so "comes first" is its own strict "<" -- with the closest hit preset to ONE ULP
+    // BEYOND the expected triangle's depth, a triangle as near as the expected one wins exactly when the reference meets it earlier; the expected triangle itself, when
+    // its leaf is reached, takes the record as it would; and the traversal ends at the first OTHER triangle that takes it (traverse_loops ANYHIT): up to there it has
+    // made the reference's decisions one by one, after that none can change the answer. A ray that misses its triangle is not traced at all.
+    if constexpr ( TERRA_SHADOW_ANYHIT && MODE == 1 && COUNT == 0 ) {
+        const V3 o_perm = v3 ( pick ( r.o, st.ix ), pick ( r.o, st.iy ), pick ( r.o, st.iz ) );
+        const float* t = T.l_tris + 12 * expected;
+        const float pa[3] = { t[st.ix], t[st.iy], t[st.iz] }, pb[3] = { t[4 + st.ix], t[4 + st.iy], t[4 + st.iz] }, pc[3] = { t[8 + st.ix], t[8 + st.iy], t[8 + st.iz] };
+        float depth;
+        if ( !watertight_permuted ( pa, pb, pc, o_perm, st, depth ) ) return 0xffffffffu;
+        Closest best; best.depth = __uint_as_float ( __float_as_uint ( depth + 0.f ) + 1u ); best.tri = 0xffffffffu;      // (depth >= 0; + 0.f: -0 -> +0)
+        if ( TERRA_FUSED_SLAB && T.fused && __all ( ray_is_tame ( r ) ) ) traverse_loops<COUNT, MODE, true, true, true> ( T, r, st, o_perm, best, c, expected );
+        else if ( __all ( ray_is_regular ( r ) ) ) traverse_loops<COUNT, MODE, true, false, true> ( T, r, st, o_perm, best, c, expected );
+        else traverse_loops<COUNT, MODE, false, false, true> ( T, r, st, o_perm, best, c, expected );
+        return best.tri;
     }
     uint32_t tri;
     if ( MODE >= 2 ) { const ClosestRanked b2 = bvh_traverse_fast<COUNT, MODE == 3> ( T, r, st, c ); tri = b2.tri; }
