@@ -47,9 +47,11 @@ def render_host(L, d, passes=1, rects=None, threads=False, seed=None):
     return out
 
 
-def render_dev(L, d, passes=1, rect=None, calls=False, shard=None, tree_mode=0):
+def render_dev(L, d, passes=1, rect=None, calls=False, shard=None, tree_mode=0, counters=True):
+    """counters=False: the kernels a client gets by default (the counting kernels are separate instantiations; a per-pixel draw-count buffer -- calls=True -- turns
+    counting on whatever the switch says)"""
     import torch
-    scene = scenes.build_scene(L, d, tree_mode=tree_mode)
+    scene = scenes.build_scene(L, d, tree_mode=tree_mode, counters=counters)
     fb = runtime.DeviceFramebuffer(d.width, d.height)
     cam = scenes.camera_of(d)
     rc = torch.zeros(d.width * d.height, dtype=torch.int32, device="cuda") if calls else None
@@ -639,6 +641,53 @@ def test_empty_and_tiny_scenes(H, L, orc_lib, devmath_mode):
     d = _tri_scene([big])
     d.objects.append(scenes.ObjectDesc(np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 2), np.float32)))
     assert same(H, render_dev(L, d)["pixels"], H.Unit("orc").render_pixels(d, want_calls=False)["pixels"])
+
+
+def _light_tie_scene(integ, occluder_first, w=40, h=28, spp=3):
+    """a light of COINCIDENT triangles (every triangle twice), a dark object that coincides with one of the light's triangles, a floor and a blocker: the light-sample
+    rays of Direct / MIS meet several triangles at exactly the depth of the one they expect, and which of them the reference's traversal prefers decides the pixel"""
+    def obj(tris, normal, mat):
+        tris = np.asarray(tris, np.float32).reshape(-1, 3, 3); n = np.zeros_like(tris); n[...] = normal
+        return scenes.ObjectDesc(tris, n, np.zeros((len(tris), 3, 2), np.float32), mat)
+    l1, l2 = [[-1, 2, 0], [1, 2, 0], [1, 2, 2]], [[-1, 2, 0], [1, 2, 2], [-1, 2, 2]]
+    light = obj([l1, l2, l1, l2], (0, -1, 0), scenes.Material(albedo=(0.5, 0.5, 0.5), emissive=(6.0, 5.0, 4.0)))
+    dark = obj([l1], (0, -1, 0), scenes.Material(albedo=(0.3, 0.6, 0.3)))
+    floor = obj([[[-2, 0, -1], [2, 0, -1], [2, 0, 3]], [[-2, 0, -1], [2, 0, 3], [-2, 0, 3]]], (0, 1, 0), scenes.Material(albedo=(0.7, 0.6, 0.5)))
+    blocker = obj([[[-0.4, 1, 0.6], [0.5, 1, 0.6], [0.5, 1, 1.4]]], (0, 1, 0), scenes.Material(albedo=(0.6, 0.3, 0.3)))
+    objs = [dark, light, floor, blocker] if occluder_first else [light, floor, blocker, dark]
+    return scenes.SceneDesc(objects=objs, width=w, height=h, spp=spp, bounces=3, integrator=integ, camera_position=(0.0, 0.9, -3.0), name="light ties")
+
+
+@pytest.mark.parametrize("integ", [1, 2])
+def test_light_sample_rays_that_meet_triangles_at_the_depth_of_their_own(H, L, orc_lib, devmath_mode, integ):
+    """the light-sample rays' shortcut (trace_device.h fast_expect / traverse_loops ANYHIT; kernels without counters) against the oracle where it is easiest to get
+    wrong: depth ties with the expected triangle, resolved by the reference's visit order"""
+    for occluder_first in (False, True):
+        d = _light_tie_scene(integ, occluder_first)
+        want = H.Unit("orc").render_pixels(d, want_calls=False)
+        assert want["pixels"].any()
+        for mode in (0, 1, 2):              # reference tree from LDS (replica), fast tree, automatic (LDS-resident: leaf-box cull)
+            for counters in (True, False):
+                got = render_dev(L, d, tree_mode=mode, counters=counters)
+                assert same(H, got["pixels"], want["pixels"]) and same(H, got["acc"], want["acc"]), (occluder_first, mode, counters)
+
+
+@pytest.mark.parametrize("counters", [False])
+def test_the_kernels_without_counters_render_the_same_frames(H, L, orc_lib, devmath_mode, counters):
+    """most tests here read the work counters and so run the counting instantiations; this one runs what a client gets: every integrator family, LDS-resident and
+    global-memory scenes, the three tree modes -- against the oracle"""
+    from test_oracle_vs_reference import soup_scene
+    cases = [scenes.cornell_box(48, 32, 3, integrator=i) for i in (0, 1, 2)] + [scenes.cornell_phong(40, 28, 2, integrator=1), scenes.cornell_spheres(40, 28, 2, integrator=2)]
+    for i in (0, 1, 2):
+        big = soup_scene(H, 1500, 90 + i, integrator=i); big.width, big.height, big.spp = 48, 32, 2
+        cases.append(big)
+    cases.append(scenes.sponza_hall(64, 36, 1, integrator=1))
+    for k, d in enumerate(cases):
+        want = H.Unit("orc").render_pixels(d, want_calls=False)
+        for mode in (0, 1, 2):
+            got = render_dev(L, d, tree_mode=mode, counters=counters)
+            assert got["stats"]["rays"] == 0                       # (the device counters really were off)
+            assert same(H, got["pixels"], want["pixels"]) and same(H, got["acc"], want["acc"]), (k, d.name, mode)
 
 
 def test_ragged_frames_and_tiles(H, L, orc_lib, devmath_mode):
