@@ -90,8 +90,14 @@ typedef struct {
     int      rccl_version;          /* ncclGetVersion() of the loaded library, 0 = not loaded (no multi-device render yet) */
     int      communicator_ranks;    /* ranks of the cached communicator */
     char     rccl_library[64];      /* the name it was loaded by */
+    uint64_t rehearsed_gathers;     /* gathers of this process that did NOT go through RCCL: the stand-in of terra_amd_debug_replicas_share_device */
 } TerraAmdMultiInfo;
 int  terra_amd_multi_info ( HTerraScene scene, TerraAmdMultiInfo* out );
+/* TEST HOOK, off by default (0): terra_amd_set_devices accepts a device listed more than once, so that a box with ONE GPU can run a scene with 2, 3, ... replicas --
+   each with its own copy of the scene (pointers rebased), its own stream, staging frame and share of the tiles -- through terra_amd_render_multi / terra_render.
+   RCCL admits one communicator rank per device, so the gather of such a set is a stand-in (one device-to-device copy per replica; TerraAmdMultiInfo::rehearsed_gathers
+   counts them, process_collectives does not): what runs is everything around the transport, what does not is the transport between distinct devices. */
+int  terra_amd_debug_replicas_share_device ( int on );
 
 /* Can this library render the scene as it stands (objects added, options set; before or after terra_scene_commit)? 0 = yes; otherwise the TerraAmdStatus the commit
    would record, with the reason in `why` (capacity bytes, always terminated; may be NULL). The reference runs any host callback a material carries

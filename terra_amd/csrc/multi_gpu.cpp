@@ -29,7 +29,7 @@ std::mutex g_lock;
 Api g_api;
 std::vector<int> g_comm_devices;          // the set the cached communicators were made for
 std::vector<ncclComm_t> g_comms;
-std::atomic<uint64_t> g_collectives { 0 };
+std::atomic<uint64_t> g_collectives { 0 }, g_rehearsed { 0 };
 
 bool load_api ( std::string& err ) {
     if ( g_api.handle ) return true;
@@ -64,6 +64,25 @@ bool gather_to_first ( const std::vector<int>& devices, const std::vector<const 
     const size_t n = devices.size();
     if ( n == 0 || send.size() != n || counts.size() != n || streams.size() != n ) { err = "gather: inconsistent arguments"; return false; }
     std::lock_guard<std::mutex> g ( g_lock );
+    // REHEARSAL (terra_amd_debug_replicas_share_device: a device listed more than once, which RCCL refuses -- one communicator rank per device): the collective's
+    // stand-in is one device-to-device copy per replica on that replica's stream, and the first stream waits for the others. Everything around the transport -- replicas,
+    // tile dealing, pack, offsets, unpack -- is the code several devices run; the transport itself is NOT RCCL here and is not counted as a collective.
+    bool shared = false;
+    for ( size_t i = 0; i < n && !shared; ++i ) for ( size_t j = 0; j < i; ++j ) if ( devices[i] == devices[j] ) { shared = true; break; }
+    if ( shared ) {
+        size_t off = 0;
+        for ( size_t k = 0; k < n; ++k ) {
+            if ( counts[k] ) {
+                hipError_t e = hipMemcpyAsync ( recv_on_first + off, send[k], counts[k] * sizeof ( float ), hipMemcpyDeviceToDevice, streams[k] );
+                hipEvent_t ev = nullptr;
+                if ( e == hipSuccess && k != 0 ) { e = hipEventCreateWithFlags ( &ev, hipEventDisableTiming ); if ( e == hipSuccess ) e = hipEventRecord ( ev, streams[k] ); if ( e == hipSuccess ) e = hipStreamWaitEvent ( streams[0], ev, 0 ); if ( ev ) ( void ) hipEventDestroy ( ev ); }
+                if ( e != hipSuccess ) { err = std::string ( "rehearsal gather: " ) + hipGetErrorString ( e ); return false; }
+            }
+            off += counts[k];
+        }
+        g_rehearsed.fetch_add ( 1, std::memory_order_relaxed );
+        return true;
+    }
     if ( !load_api ( err ) || !comms_for ( devices, err ) ) return false;
     // one group: rank r sends its packed tiles to rank 0, rank 0 receives every rank's -- its own included, a copy inside device 0, so that one rank
     // runs exactly the calls that eight run
@@ -80,6 +99,7 @@ bool gather_to_first ( const std::vector<int>& devices, const std::vector<const 
 
 void forget_communicators() { std::lock_guard<std::mutex> g ( g_lock ); drop_comms_locked(); }
 uint64_t collectives_issued() { return g_collectives.load ( std::memory_order_relaxed ); }
+uint64_t gathers_rehearsed() { return g_rehearsed.load ( std::memory_order_relaxed ); }
 int rccl_version() { std::lock_guard<std::mutex> g ( g_lock ); int v = 0; if ( g_api.GetVersion ) ( void ) g_api.GetVersion ( &v ); return v; }
 std::string rccl_path() { std::lock_guard<std::mutex> g ( g_lock ); return g_api.path; }
 int communicator_ranks() { std::lock_guard<std::mutex> g ( g_lock ); return ( int ) g_comms.size(); }

@@ -13,6 +13,7 @@ bool gather_to_first ( const std::vector<int>& devices, const std::vector<const 
                        const std::vector<hipStream_t>& streams, std::string& err );
 void forget_communicators();          // destroys the cached communicators (the device set changed)
 uint64_t collectives_issued();        // gathers issued by this process so far
+uint64_t gathers_rehearsed();         // ... and gathers that went through the rehearsal's stand-in instead (a device listed twice: terra_amd_debug_replicas_share_device)
 int rccl_version();                   // ncclGetVersion of the loaded library (0: not loaded yet)
 std::string rccl_path();              // the name it was loaded by
 int communicator_ranks();             // ranks of the cached communicator (0: none)

@@ -87,12 +87,14 @@ extern "C" int terra_amd_get_device ( void ) { return g_device; }
 // the staging frame of terra_render() / terra_amd_render_multi() and receives the gather.
 static std::mutex g_devices_lock;
 static std::vector<int> g_devices;
+static std::atomic<int> g_replicas_share_device { 0 };       // TEST HOOK (terra_amd_debug_replicas_share_device)
+extern "C" int terra_amd_debug_replicas_share_device ( int on ) { g_replicas_share_device.store ( on ? 1 : 0 ); return 0; }
 extern "C" int terra_amd_set_devices ( const int* devices, int count ) {
     if ( count < 0 || count > 64 || ( count > 0 && !devices ) ) return fail ( kTerraAmdErrBadArgument, "terra_amd_set_devices: %d devices", count );
     const int n = terra_amd_device_count();
     for ( int i = 0; i < count; ++i ) {
         if ( devices[i] < 0 || devices[i] >= n ) return fail ( kTerraAmdErrNoDevice, "device %d not available (%d visible)", devices[i], n );
-        for ( int j = 0; j < i; ++j ) if ( devices[j] == devices[i] ) return fail ( kTerraAmdErrBadArgument, "device %d is listed twice", devices[i] );
+        for ( int j = 0; j < i && !g_replicas_share_device.load(); ++j ) if ( devices[j] == devices[i] ) return fail ( kTerraAmdErrBadArgument, "device %d is listed twice", devices[i] );
     }
     std::lock_guard<std::mutex> g ( g_devices_lock );
     const std::vector<int> now ( devices, devices + count );
@@ -1112,6 +1114,15 @@ static int replicate_scene ( Scene* s ) {
             q.dev.env_f = emove ( s->dev.env_f ); q.dev.env_cdf = emove ( s->dev.env_cdf ); q.dev.env_row_f = emove ( s->dev.env_row_f ); q.dev.env_row_cdf = emove ( s->dev.env_row_cdf );
         }
         q.dev.sincos24 = sincos_table_of ( q.device );
+        // self-check, independent of the list above: no 8-byte word of the replica's scene record may still be an address inside the PRIMARY's blob (or its
+        // environment tables) -- a pointer member added to DevScene and forgotten here would be exactly that, and on a single box it would even keep working
+        {
+            uint64_t words[ ( sizeof ( DevScene ) + 7 ) / 8] = { 0 }; memcpy ( words, &q.dev, sizeof ( DevScene ) );
+            const uint64_t b0 = ( uint64_t ) ( uintptr_t ) base0, b1 = b0 + s->blob_bytes, e0 = ( uint64_t ) ( uintptr_t ) s->d_env_dist, e1 = e0 + s->env_dist_floats * sizeof ( float );
+            for ( size_t i = 0; i < sizeof ( DevScene ) / 8; ++i )
+                if ( ( words[i] >= b0 && words[i] < b1 ) || ( e0 && words[i] >= e0 && words[i] < e1 ) )
+                    return fail ( kTerraAmdErrLaunch, "scene replica for device %d: byte %zu of its scene record still points into the primary device's copy (a pointer that replicate_scene does not rebase)", q.device, i * 8 );
+        }
     }
     HIP_TRY ( hipSetDevice ( s->device ), kTerraAmdErrNoDevice );
     return 0;
@@ -1664,7 +1675,7 @@ extern "C" int terra_amd_multi_info ( HTerraScene h, TerraAmdMultiInfo* out ) {
     out->replicas = s->device_ok ? ( int ) s->extra.size() + 1 : 0;
     std::lock_guard<std::mutex> lock ( s->multi_lock );
     out->gathers = s->multi ? s->multi->gathers : 0; out->last_gather_bytes = s->multi ? s->multi->last_gather_bytes : 0;
-    out->process_collectives = multigpu::collectives_issued(); out->rccl_version = multigpu::rccl_version(); out->communicator_ranks = multigpu::communicator_ranks();
+    out->process_collectives = multigpu::collectives_issued(); out->rehearsed_gathers = multigpu::gathers_rehearsed(); out->rccl_version = multigpu::rccl_version(); out->communicator_ranks = multigpu::communicator_ranks();
     snprintf ( out->rccl_library, sizeof out->rccl_library, "%s", multigpu::rccl_path().c_str() );
     return 0;
 }

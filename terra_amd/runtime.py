@@ -77,6 +77,7 @@ _EXTRA = {
     "terra_amd_shard_owner": (C.c_int, [C.c_size_t, C.c_int]),
     "terra_amd_render_multi": (C.c_int, [C.POINTER(api.TerraCamera), C.c_void_p, C.POINTER(api.TerraFramebuffer)] + [C.c_size_t] * 5),
     "terra_amd_multi_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "terra_amd_debug_replicas_share_device": (C.c_int, [C.c_int]),
     "terra_amd_set_work_counters": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_work_counters": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sampler_integration": (C.c_int, [C.c_void_p, C.c_int]),
@@ -147,7 +148,7 @@ def first_error():
 class MultiInfo(C.Structure):
     """TerraAmdMultiInfo (include/terra_amd.h)"""
     _fields_ = [("devices", C.c_int), ("device", C.c_int * 16), ("replicas", C.c_int), ("gathers", C.c_uint64), ("last_gather_bytes", C.c_uint64),
-                ("process_collectives", C.c_uint64), ("rccl_version", C.c_int), ("communicator_ranks", C.c_int), ("rccl_library", C.c_char * 64)]
+                ("process_collectives", C.c_uint64), ("rccl_version", C.c_int), ("communicator_ranks", C.c_int), ("rccl_library", C.c_char * 64), ("rehearsed_gathers", C.c_uint64)]
 
 
 class DeviceFramebuffer:

@@ -3,7 +3,9 @@ terra_amd_multi_info): the layout of the reference's client -- one process, tile
 
 CPU: the tile -> device map for 2, 4 and 8 devices, argument checking. GPU (one device on the test box): the multi-device code path with a device set
 of ONE -- replica bookkeeping, communicator, pack, the RCCL gather (issued, not short-circuited), unpack, one copy to the host -- against terra_render()
-and the oracle, bit for bit. More than one device has never run (no multi-GPU box is available to the build): DESIGN.md "Multi-GPU" says so.
+and the oracle, bit for bit; and a REHEARSAL of 2, 3 and 5 replicas on the one device (terra_amd_debug_replicas_share_device): every replica its own copy of the
+scene with rebased pointers, its own stream and share of the tiles, the gather a stand-in (RCCL admits one rank per device). The RCCL transport between DISTINCT
+devices has never run (no multi-GPU box is available to the build): DESIGN.md "Multi-GPU" says so.
 """
 import ctypes as C
 
@@ -87,3 +89,43 @@ def test_multi_device_path_with_one_device_equals_terra_render_and_the_oracle(H,
             fb.destroy(); fb2.destroy(); Lg.scene_destroy(scene)
         finally:
             Lg.set_devices(None, 0)
+
+
+@pytest.mark.gpu
+def test_rehearsal_of_several_replicas_on_one_device(H, orc_lib, devmath_mode):
+    """2, 3 and 5 replicas of a scene on device 0: what several devices run, except the transport. Scenes chosen for what a replica has to carry: the fast tree and
+    its triangle soup, a texture (descriptors rebased), the environment's sampling tables (a second allocation), the light tables of Direct + MIS."""
+    import torch  # noqa: F401
+    from test_oracle_vs_reference import soup_scene
+    Lg = runtime.load()
+    rs = np.random.RandomState(5)
+    big = soup_scene(H, 1500, 91, integrator=2); big.width, big.height, big.spp = 136, 100, 2
+    env = scenes.cornell_box(132, 72, 2, integrator=1)
+    env.environment_texture = scenes.TextureDesc(rs.uniform(0, 3, size=(6, 11, 3)).astype(np.float32), address_mode=0); env.environment_lighting = True; env.environment_sampling = True
+    tex = scenes.cornell_textured(96, 64, 2) if hasattr(scenes, "cornell_textured") else scenes.cornell_phong(96, 64, 2, integrator=1)
+    runtime.check(Lg.debug_replicas_share_device(1))
+    try:
+        for d in (big, env, tex):
+            want = H.Unit("orc").render_pixels(d, passes=2, want_calls=False)
+            for world in (2, 3, 5):
+                devs = (C.c_int * world)(*([0] * world))
+                Lg.clear_error()
+                runtime.check(Lg.set_devices(devs, world), "terra_amd_set_devices")
+                scene = scenes.build_scene(Lg, d)
+                assert runtime.last_error() == "", runtime.last_error()
+                fb = api.Framebuffer(Lg, d.width, d.height); cam = scenes.camera_of(d)
+                before = runtime.MultiInfo(); runtime.check(Lg.multi_info(scene, C.byref(before)))
+                assert before.devices == world and before.replicas == world
+                for _ in range(2):
+                    runtime.check(Lg.render_multi(C.byref(cam), scene, C.byref(fb.fb), 0, 0, d.width, d.height, 32), runtime.last_error())
+                info = runtime.MultiInfo(); runtime.check(Lg.multi_info(scene, C.byref(info)))
+                assert info.gathers == 2 and info.rehearsed_gathers >= before.rehearsed_gathers + 2 and info.process_collectives == before.process_collectives      # (the stand-in, and it says so)
+                assert np.array_equal(H.bits(fb.results["acc"]), H.bits(want["acc"])) and np.array_equal(fb.results["samples"], want["samples"]), (d.name, world)
+                nan = np.isnan(want["pixels"])
+                assert np.array_equal(H.bits(fb.pixels)[~nan], H.bits(want["pixels"])[~nan]), (d.name, world)
+                fb.destroy(); Lg.scene_destroy(scene)
+    finally:
+        Lg.set_devices(None, 0); Lg.debug_replicas_share_device(0)
+    two = (C.c_int * 2)(0, 0)
+    assert Lg.set_devices(two, 2) < 0 and "twice" in runtime.last_error()          # the hook is off again
+    Lg.clear_error()
