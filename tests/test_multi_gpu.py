@@ -124,6 +124,30 @@ def test_rehearsal_of_several_replicas_on_one_device(H, orc_lib, devmath_mode):
                 nan = np.isnan(want["pixels"])
                 assert np.array_equal(H.bits(fb.pixels)[~nan], H.bits(want["pixels"])[~nan]), (d.name, world)
                 fb.destroy(); Lg.scene_destroy(scene)
+        # the drop-in entry on a scene with two replicas: a call that covers enough of the frame is sharded over them (include/terra_amd.h terra_amd_set_devices),
+        # a tile-sized call goes to one replica -- the calling thread's -- whole
+        d = scenes.cornell_box(512, 288, 1, integrator=1)
+        want = H.Unit("orc").render_pixels(d, want_calls=False)
+        runtime.check(Lg.set_devices((C.c_int * 2)(0, 0), 2))
+        scene = scenes.build_scene(Lg, d); cam = scenes.camera_of(d)
+        fb = api.Framebuffer(Lg, d.width, d.height)
+        g0 = runtime.MultiInfo(); runtime.check(Lg.multi_info(scene, C.byref(g0)))
+        Lg.render(C.byref(cam), scene, C.byref(fb.fb), 0, 0, d.width, d.height)
+        g1 = runtime.MultiInfo(); runtime.check(Lg.multi_info(scene, C.byref(g1)))
+        assert runtime.last_error() == "" and g1.gathers == g0.gathers + 1
+        assert np.array_equal(H.bits(fb.results["acc"]), H.bits(want["acc"]))
+        fb2 = api.Framebuffer(Lg, d.width, d.height)
+        import threading
+        def tiles(rows):
+            for ty in rows:
+                for tx in range(0, d.width, 128):
+                    Lg.render(C.byref(cam), scene, C.byref(fb2.fb), tx, ty, min(128, d.width - tx), min(96, d.height - ty))
+        th = [threading.Thread(target=tiles, args=(range(k * 96, d.height, 192),)) for k in range(2)]          # two client threads: each lands on its own replica
+        [t.start() for t in th]; [t.join() for t in th]
+        g2 = runtime.MultiInfo(); runtime.check(Lg.multi_info(scene, C.byref(g2)))
+        assert runtime.last_error() == "" and g2.gathers == g1.gathers              # tile-sized calls are not sharded
+        assert np.array_equal(H.bits(fb2.results["acc"]), H.bits(want["acc"]))
+        fb.destroy(); fb2.destroy(); Lg.scene_destroy(scene)
     finally:
         Lg.set_devices(None, 0); Lg.debug_replicas_share_device(0)
     two = (C.c_int * 2)(0, 0)
