@@ -228,7 +228,9 @@ int  terra_amd_get_environment_sampling ( HTerraScene scene );
    The device-side counters (rays, nodes, box_tests, tri_tests, hits, rand_calls, attr_fetches, tri_culled) are INSTRUMENTATION and off by default, like the
    reference's TERRA_PROFILE (src/Terra.c:564,634,1643: compiled out unless defined): terra_amd_set_work_counters(scene, 1) makes subsequent render calls count
    (a launch parameter, no commit needed), at 4-6 % of the render time; a call that is handed a per-pixel draw-count buffer counts regardless. samples, pixels
-   and launches are kept by the host either way. */
+   and launches are kept by the host either way. rays, hits, rand_calls and attr_fetches are functions of the image (equal in every tree mode, run after run); nodes,
+   box_tests and tri_tests count the work the chosen traversal did, and on the fast tree -- where a lane that holds a leaf descends on speculatively while it waits
+   for its wave's triangle step -- they vary by a fraction of a percent with how the frame's jobs happened to be dealt to the waves. */
 int terra_amd_set_work_counters ( HTerraScene scene, int on );
 int terra_amd_get_work_counters ( HTerraScene scene );
 typedef struct {

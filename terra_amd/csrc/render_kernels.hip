@@ -743,7 +743,7 @@ size_t terra_lds_bytes ( const DevRenderParams& p ) {
     return ( size_t ) ( p.stack_depth + p.leaf_cap + ( p.lds_mode == 1 ? TERRA_AUX_WORDS_LDS : TERRA_AUX_WORDS ) ) * 1024 + ( size_t ) p.lds_nodes * TERRA_LDS_NODE_BYTES + ( size_t ) p.lds_tris * ( 48 + 64 )
            + ( p.lds_mode == 1 ? scene_extra_lds_bytes ( p.scene.n_objects, p.scene.n_lights, p.scene.n_tris ) : 0 );
 }
-// fast tree (MODE 2 / 3): nothing is staged. A lane holds at most one leaf (in a register), so there is no leaf list. The stack: its first TERRA_FAST_STACK_LDS entries
+// fast tree (MODE 2 / 3): nothing is staged. A lane holds at most two leaves (in registers: the one it tests, the next one), so there is no leaf list. The stack: its first TERRA_FAST_STACK_LDS entries
 // in LDS (1 KB per entry and block), the rest -- up to the tree's worst case, which a ray almost never reaches -- in HBM, 4 bytes per entry and resident lane
 // (DevRenderParams::stack_spill, part of the launch's scratch: trace_device.h fast_push / fast_pop). Depth no longer decides whether a tree can be launched.
 // (Rounds 2-3 staged the first 64 nodes as plain 64-byte nodes read through a flat load: +3.7 % then. Flat loads go through the texture addresser like global ones,
