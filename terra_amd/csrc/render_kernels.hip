@@ -200,7 +200,8 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
 #ifndef TERRA_DECOUPLED_FAST_DIRECT  // ... also on the fast tree (MODE 2): hall, 32 spp, 112.0 -> 108.2 ms
 #define TERRA_DECOUPLED_FAST_DIRECT 1
 #endif
-#ifndef TERRA_DECOUPLED_FAST_MIS     // Direct + MIS on the fast tree is faster coupled (hall, 32 spp: 168.6 ms against 187.7 decoupled; profiles/r02_measurements/ab_fast_light.log)
+#ifndef TERRA_DECOUPLED_FAST_MIS     // Direct + MIS on the fast tree is faster coupled (hall, 32 spp: 168.6 ms against 187.7 decoupled, profiles/r02_measurements/ab_fast_light.log; round 4, with the
+                                     // light-sample rays' shortcut in both: 100.5 against 117.5, sphere scene 128 spp 157.8 against 162.4, profiles/r04_measurements/ab_fast_tree_knobs.log)
 #define TERRA_DECOUPLED_FAST_MIS 0
 #endif
 #define TERRA_DECOUPLED_DIRECT(I, M, K) ( TERRA_DECOUPLED_DIRECT_ENABLE && ( ( M ) == 0 || ( TERRA_DECOUPLED_FAST_DIRECT && ( M ) >= 2 ) ) && ( I ) == 1 && ( ( K ) & TERRA_KIND_TEX ) == 0 )

@@ -623,7 +623,7 @@ TD void order_pair ( uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb ) {
     ka = k0; kb = k1; ca = c0; cb = c1;
 }
 #define TERRA_FAST_ROOT_IN_HAND 0u
-TD bool fast_holds_leaf ( uint32_t hand ) { return ( int ) hand < -1; }          // (DEV_CHILD_EMPTY is -1; no leaf word is: a leaf has at most 4 triangles, so bits 29-30 of its count field are clear)
+// (a leaf word in `hand` is recognised by ( int ) hand < -1: DEV_CHILD_EMPTY is -1 and no leaf word is -- a leaf has at most 4 triangles, so bits 29-30 of its count field are clear)
 TD bool fast_traversing ( const Tracer& T, uint32_t hand, uint32_t held, const int* top ) { return ( hand != DEV_CHILD_EMPTY ) | ( top != T.stack ) | ( held != 0u ); }
 template <int COUNT>
 TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& st, V3 o_perm, ClosestRanked& best, int*& top, uint32_t& hand, uint32_t& held, int exit_active, Counters& c, bool checked = false, bool anyhit = false ) {
