@@ -67,6 +67,11 @@ __global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float s
 #define I_CMPS(i) asm volatile ( "v_cmp_gt_f32_e64 s[22:23], %0, %1" : : "v"( a[i] ), "v"( b ) : "s22", "s23" );
 #define I_BFE(i) asm volatile ( "v_bfe_u32 %0, %0, 3, 5" : "+v"( u[i] ) );
 #define I_ADDC(i) asm volatile ( "v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"( u[i] ) : "v"( ub ) : "vcc" );
+#define C_VCC64(i) asm volatile ( "v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"( u[i] ) : "v"( ub ) );
+#define CC_VCC(i) asm volatile ( "v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"( u[i] ) : "v"( a[i] ), "v"( b ), "v"( ub ) : "vcc" );
+#define CC_SGPR(i) asm volatile ( "v_cmp_gt_f32_e64 s[22:23], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %3, s[22:23]" : "+v"( u[i] ) : "v"( a[i] ), "v"( b ), "v"( ub ) : "s22", "s23" );
+#define CC_VCC_FAR(i) asm volatile ( "v_cmp_gt_f32 vcc, %1, %2\n\tv_add_f32 %1, %1, %2\n\tv_mul_f32 %4, %4, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"( u[i] ), "+v"( a[i] ) : "v"( b ), "v"( ub ), "v"( a[( i + 8 ) & 15] ) : "vcc" );
+#define CC_SGPR_FAR(i) asm volatile ( "v_cmp_gt_f32_e64 s[22:23], %1, %2\n\tv_add_f32 %1, %1, %2\n\tv_mul_f32 %4, %4, %2\n\tv_cndmask_b32_e64 %0, %0, %3, s[22:23]" : "+v"( u[i] ), "+v"( a[i] ) : "v"( b ), "v"( ub ), "v"( a[( i + 8 ) & 15] ) : "s22", "s23" );
 #define S_SALU(i) asm volatile ( "s_add_u32 s20, s20, 1" : : : "s20" );
 #define F_MIX(i) asm volatile ( "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"( a[i] ) : "v"( u[i] ), "v"( b ) );
 #define V_PERM(i) asm volatile ( "v_perm_b32 %0, %0, %0, %1" : "+v"( u[i] ) : "v"( ub ) );
@@ -127,6 +132,11 @@ __global__ __launch_bounds__ ( 256 ) void bench ( float* out, int iters, float s
         if ( OP == 47 ) { REP16 ( I_CMPS ) }
         if ( OP == 48 ) { REP16 ( I_BFE ) }
         if ( OP == 49 ) { REP16 ( I_ADDC ) }
+        if ( OP == 50 ) { REP16 ( C_VCC64 ) }
+        if ( OP == 51 ) { REP16 ( CC_VCC ) }
+        if ( OP == 52 ) { REP16 ( CC_SGPR ) }
+        if ( OP == 53 ) { REP16 ( CC_VCC_FAR ) }
+        if ( OP == 54 ) { REP16 ( CC_SGPR_FAR ) }
     }
     float s = 0; for ( int i = 0; i < 16; ++i ) s += a[i] + ( float ) d[i] + ( float ) q[i] + ( float ) u[i];
     if ( s == 12345.678f ) out[0] = s;
@@ -160,6 +170,10 @@ int main ( int argc, char** argv ) {
     printf ( "%s CUs %d clock %.2f GHz\n", p.name, p.multiProcessorCount, ghz );
     float* out; hipMalloc ( &out, 4 );
 #define R(op, n) run<op> ( n, w, out, ghz, p.multiProcessorCount );
+    if ( argc > 1 && std::string ( argv[1] ) == "select" ) {       // the select forms: mask in VCC against mask in an SGPR pair (the 51 - 54 streams hold 2 / 4 instructions per slot: divide their cycles accordingly)
+        for ( int w : { 4 } ) { R ( 34, "v_cndmask vcc" ) R ( 50, "v_cndmask_e64 vcc" ) R ( 35, "v_cndmask sgpr" ) R ( 51, "cmp+cndmask vcc (x2)" ) R ( 52, "cmp+cndmask sgpr (x2)" ) R ( 53, "cmp,add,mul,cndmask vcc (x4)" ) R ( 54, "cmp,add,mul,cndmask sgpr (x4)" ) }
+        return 0;
+    }
     if ( argc > 1 && std::string ( argv[1] ) == "mix" ) {          // only the mixed streams, at the occupancies the kernels run at
         for ( int w : { 4, 5 } ) { R ( 100, "mix: headline kernel" ) R ( 101, "mix: 4-wide node step" ) R ( 2, "v_fma_f32" ) R ( 0, "v_add_f32" ) R ( 35, "v_cndmask sgpr" ) }
         return 0;
