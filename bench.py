@@ -75,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="cornell_1080p_512spp")
     ap.add_argument("--integrator", default="", choices=["", "simple", "direct", "mis"], help="override the workload's integrator (the result is then NOT the headline config)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
+    ap.add_argument("--bounces", type=int, default=-1, help="override the maximum number of bounces (the result is then NOT the headline config; 0 = camera rays only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the `host_api` block (the same frame through terra_render() on a host framebuffer)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other configurations)")
@@ -723,6 +724,8 @@ def main():
     d = workload(args.workload, args.spp)
     if args.integrator:
         d.integrator = INTEGRATORS[args.integrator]
+    if args.bounces >= 0:
+        d.bounces = args.bounces
     integ_name = {0: "simple", 1: "direct", 2: "mis"}.get(d.integrator, str(d.integrator))
     m = measure(c, d, args.tree, args.sample_split, args.steps, args.warmup, check=args.check or (world > 1 and not args.no_check))
 
@@ -750,7 +753,7 @@ def main():
             out["host_api"]["multi_device"] = multi_device_block(args.workload)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
-        headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator) and args.tree == "auto" and args.sample_split == DEFAULT_SPLIT
+        headline = args.workload == "cornell_1080p_512spp" and not (args.spp or args.integrator or args.bounces >= 0) and args.tree == "auto" and args.sample_split == DEFAULT_SPLIT
         if world == 1 and not c.dist_on and headline and not args.no_workloads:
             extra = []; cpu_cache = {}
             for name, tree, integ, split, steps, warmup, prewarm, cpu_s in EXTRA_WORKLOADS:
