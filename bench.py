@@ -76,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--integrator", default="", choices=["", "simple", "direct", "mis"], help="override the workload's integrator (the result is then NOT the headline config)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (the result is then NOT the headline config)")
     ap.add_argument("--bounces", type=int, default=-1, help="override the maximum number of bounces (the result is then NOT the headline config; 0 = camera rays only)")
+    ap.add_argument("--job-order", type=int, default=-1, choices=[-1, 0, 1], help="terra_amd_set_job_order: -1 the library's default (on), 0 / 1 to A/B it (the frame does not change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the `host_api` block (the same frame through terra_render() on a host framebuffer)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other configurations)")
@@ -470,6 +471,8 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
     runtime.check(lib.set_sample_split(scene, split), "terra_amd_set_sample_split")
+    if getattr(c, "job_order", -1) >= 0:
+        runtime.check(lib.set_job_order(scene, c.job_order), "terra_amd_set_job_order")
     ti = runtime.TraversalInfo(); runtime.check(lib.traversal_info(scene, C.byref(ti)))
     info = runtime.SceneInfo(); runtime.check(lib.scene_info(scene, C.byref(info)))
     cam = scenes.camera_of(d)
@@ -717,6 +720,7 @@ def main():
         sys.exit(self_launch(args, argv))
     import torch  # noqa: F401  before the library: it must bind to the HIP runtime torch loads
     c = setup(args)
+    c.job_order = args.job_order
     world, rank = c.world, c.rank
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")

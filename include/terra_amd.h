@@ -187,6 +187,17 @@ int  terra_amd_debug_fast_stack_lds ( HTerraScene scene, int entries );
 int  terra_amd_set_sample_split ( HTerraScene scene, int split );
 int  terra_amd_get_sample_split ( HTerraScene scene );
 
+/* Job order, on by default. A render launch on a scene that is staged whole in the compute units' local memory hands its (pixel, chunk) jobs to the lanes of a persistent
+   grid, and ends when the longest of the jobs in flight at the end is done: about a millisecond on a Cornell-box frame whatever the launch's share of it -- a seventh of the
+   time of a 1/8 shard. Such a launch therefore first classifies its 16x16 pixel blocks with five camera rays each (centre and corners) and hands out the blocks some camera
+   ray hits first, the blocks whose camera rays all leave the scene -- short jobs: one traversal per sample, nothing to shade -- last. Which lane runs a job, and when,
+   has no influence on what the job computes: the framebuffer is the same bit for bit (tests/test_job_order.py). Launches of fewer than 256 pixel blocks (a 256 x 256
+   rectangle) keep the order of the numbering: a tile-sized call is usually one of several in flight, whose work hides its tail, and the two small kernels that make the
+   order would queue behind the other callers' grids. terra_amd_set_job_order(scene, 0) keeps the order of the numbering everywhere, 2 orders launches of any size
+   (what the tests use on small frames); 1 is the default. A launch parameter: no commit needed. */
+int  terra_amd_set_job_order ( HTerraScene scene, int on );
+int  terra_amd_get_job_order ( HTerraScene scene );
+
 /* Environment lighting, off by default. The reference evaluates scene options' environment_map for a ray
    that leaves the scene, multiplies the throughput by it and then drops the result: the line that would
    add it is commented out (src/Terra.c:1053-1058), so the environment never reaches the image. With

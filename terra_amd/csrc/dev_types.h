@@ -191,6 +191,10 @@ struct DevRenderParams {
     // shard) * split; *job_queue (zeroed before the launch) hands out the jobs beyond the ones the launched lanes start with
     uint32_t job_blocks;
     uint32_t* job_queue;
+    // job order (launches that key their streams ahead, render_kernels.hip "job order"): the 16x16 pixel blocks of the launch are handed out in the order
+    // block_order[0 .. blocks) -- the blocks some camera ray hits first, the blocks whose camera rays all leave the scene last, so that the launch ends on short jobs --
+    // and block_order[blocks + b] is where pixel block b went (the resolve kernel finds the block's sums there). nullptr: the order of the numbering.
+    const uint32_t* block_order;
     // the job decode's divisions by launch constants as multiplications: ceil(2^32 / d) (0 for d == 1) for d = (blocks per tile)^2, tiles per row of the
     // rectangle, blocks per tile row (the host refuses a launch in which some product n * d could reach 2^32)
     uint32_t job_div_bpt2, job_div_tiles_x, job_div_bpt, job_tiles_x;

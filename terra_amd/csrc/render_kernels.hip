@@ -137,12 +137,13 @@ __global__ __launch_bounds__ ( 256 ) void terra_resolve_kernel ( DevRenderParams
     if ( p.job_queue && blockIdx.x == 0 && threadIdx.x == 0 ) *p.job_queue = 0u;       // the render kernel is done with its queue: leave the word ready for the next launch on this scratch (scene_host.cpp launch_render)
     uint32_t px, py;
     if ( !block_pixel ( p, blockIdx.x, threadIdx.x, px, py ) ) return;
+    const uint32_t vb = p.block_order ? p.block_order[gridDim.x + blockIdx.x] : blockIdx.x;      // where the job order put this pixel block: its sums are stored under that number
     const size_t pix = ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x );
     DevResult* results = reinterpret_cast<DevResult*> ( p.results );
     DevResult out = results[pix];
     uint32_t calls = 0;
     for ( uint32_t j = 0; j < p.split; ++j ) {
-        const float4 q = p.partials[ ( ( size_t ) j * gridDim.x + blockIdx.x ) * 256 + threadIdx.x];
+        const float4 q = p.partials[ ( ( size_t ) j * gridDim.x + vb ) * 256 + threadIdx.x];
         out.acc[0] = out.acc[0] + q.x; out.acc[1] = out.acc[1] + q.y; out.acc[2] = out.acc[2] + q.z;
         calls += __float_as_uint ( q.w );
     }
@@ -348,10 +349,14 @@ struct Jobs { uint32_t px, py, s; bool exhausted; uint32_t base; };      // base
 TD uint32_t magic_div ( uint32_t n, uint32_t magic ) { return magic ? __umulhi ( n, magic ) : n; }
 // block_pixel() for a job, with the divisions by launch constants done by multiplication (p.job_div_*; the host refuses launches whose dividends are too large
 // for that -- no plain-division fallback here: its hoisted reciprocals would sit in registers through the whole render loop)
+TD bool job_pixel_of_block ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint32_t& px, uint32_t& py );
 TD bool job_pixel ( const DevRenderParams& p, uint32_t job, uint32_t& px, uint32_t& py, uint32_t& chunk ) {
-    const uint32_t vblock = job >> 8, tid = job & 255u;
+    const uint32_t vblock = job >> 8;
     chunk = vblock & ( p.split - 1 );
-    const uint32_t blk = vblock >> p.split_log2;
+    return job_pixel_of_block ( p, vblock >> p.split_log2, job & 255u, px, py );
+}
+// thread tid's pixel of 16x16 pixel block blk of the launch
+TD bool job_pixel_of_block ( const DevRenderParams& p, uint32_t blk, uint32_t tid, uint32_t& px, uint32_t& py ) {
     const uint32_t bpt = p.tile_size >> 4, bpt2 = bpt * bpt;
     const uint32_t k = magic_div ( blk, p.job_div_bpt2 ), b = blk - k * bpt2;
     const uint32_t t = p.rank + k * p.world;
@@ -929,12 +934,78 @@ uint32_t terra_render_blocks ( const DevRenderParams& p ) {
 // numbered like the render kernel's jobs; a job whose pixel lies outside the rectangle has no entry (nobody reads it).
 __global__ __launch_bounds__ ( 256 ) void terra_job_streams_kernel ( DevRenderParams p ) {
     const uint32_t job = blockIdx.x * 256u + threadIdx.x;
-    uint32_t px, py, chunk;
-    if ( !job_pixel ( p, job, px, py, chunk ) ) { p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( 0u, 0u, 0xffffffffu, 0u ); return; }
+    uint32_t px, py;
+    const uint32_t vblock = job >> 8, chunk = vblock & ( p.split - 1 ), v = vblock >> p.split_log2;
+    if ( !job_pixel_of_block ( p, p.block_order ? p.block_order[v] : v, job & 255u, px, py ) ) { p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( 0u, 0u, 0xffffffffu, 0u ); return; }
     const int prior_samples = reinterpret_cast<const DevResult*> ( p.results ) [ ( size_t ) ( py - p.st_y ) * p.st_pitch + ( px - p.st_x )].samples;      // keys the streams; the sum itself is the resolve kernel's business
     const PixelStreams rs = trng_pixel_streams ( p.frame_seed, ( uint64_t ) py * p.fb_w + px, ( uint64_t ) ( uint32_t ) prior_samples + ( uint64_t ) chunk * p.chunk_spp );
     p.job_streams[2 * ( size_t ) job] = make_uint4 ( ( uint32_t ) rs.a.state, ( uint32_t ) ( rs.a.state >> 32 ), ( uint32_t ) rs.b.state, ( uint32_t ) ( rs.b.state >> 32 ) );
     p.job_streams[2 * ( size_t ) job + 1] = make_uint4 ( ( uint32_t ) rs.b.inc, ( uint32_t ) ( rs.b.inc >> 32 ), px | ( py << 16 ), ( uint32_t ) prior_samples );      // (frames of up to 65,535 x 65,535: scene_host.cpp launch_render refuses larger ones)
+}
+// ---- job order ------------------------------------------------------------------------------------------------------------
+// A persistent launch ends with its TAIL: when the queue runs dry every lane is inside a job, and the kernel lasts until the longest of those is done -- about 1.1 ms on the
+// Cornell frame whatever the launch's share of it (profiles/r04_measurements/launch_fixed_cost.log), a seventh of a 1/8 shard. What a job costs is mostly decided by whether
+// its pixel's camera rays hit anything: a sample whose camera ray leaves the scene is one short traversal, nothing to shade, no bounce. So the launches that key their
+// streams ahead (LDS-resident scenes: a few dozen triangles) first CLASSIFY their 16x16 pixel blocks -- five camera rays per block (centre and corners, no jitter) against
+// every triangle, the test the traversal applies -- and hand the blocks out hit ones first, empty ones last: the long jobs are under way while there is still plenty of
+// short work to fill the lanes beside them, and the launch ends on jobs of a few ray iterations. Only the ORDER in which jobs are taken changes: which job a lane runs
+// never mattered (render_kernels.hip "jobs"), a block's sums are stored under its place in the order and the resolve kernel looks them up there (DevRenderParams::block_order).
+__global__ __launch_bounds__ ( 256 ) void terra_block_class_kernel ( DevRenderParams p, uint32_t nblocks, uint32_t* cls ) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if ( b >= nblocks ) return;
+    const float4* tris = reinterpret_cast<const float4*> ( p.scene.tris );
+    const V3 cam_pos = v3p ( p.cam_pos );
+    bool hit = false;
+    for ( uint32_t k = 0; k < 5 && !hit; ++k ) {
+        const uint32_t lx = k == 0 ? 8u : ( ( k - 1 ) & 1u ) * 15u, ly = k == 0 ? 8u : ( ( k - 1 ) >> 1 ) * 15u;
+        const uint32_t tid = ( ( ( lx >> 3 ) | ( ( ly >> 3 ) << 1 ) ) << 6 ) | ( lx & 7u ) | ( ( ly & 7u ) << 3 );      // (block_pixel's thread -> pixel map, inverted)
+        uint32_t px, py;
+        if ( !job_pixel_of_block ( p, b, tid, px, py ) ) continue;          // (a pixel outside the rectangle)
+        Ray r = make_ray ( cam_pos, camera_sample ( p, px, py, 0.5f, 0.5f ) );
+        r.o = r.o + r.d * 0.001f;
+        const RayState st = ray_state_init ( r );
+        for ( uint32_t t = 0; t < p.scene.n_tris && !hit; ++t ) {
+            const float4 a = tris[3 * t], bb = tris[3 * t + 1], cc = tris[3 * t + 2];
+            TriHit h;
+            hit = watertight ( r, st, v3 ( a.x, a.y, a.z ), v3 ( bb.x, bb.y, bb.z ), v3 ( cc.x, cc.y, cc.z ), h );
+        }
+    }
+    cls[b] = hit ? 0u : 1u;
+}
+// order[0 .. n): the blocks of class 0 in their own order, then those of class 1; order[n + b]: block b's place. One block of 256 threads.
+__global__ __launch_bounds__ ( 256 ) void terra_block_order_kernel ( uint32_t n, const uint32_t* cls, uint32_t* order ) {
+    __shared__ uint32_t before0[256];
+    __shared__ uint32_t total0;
+    const uint32_t t = threadIdx.x, per = ( n + 255u ) / 256u;
+    const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    uint32_t c0 = 0;
+    for ( uint32_t i = lo; i < hi; ++i ) c0 += cls[i] == 0u;
+    before0[t] = c0;
+    __syncthreads();
+    if ( t == 0 ) { uint32_t run = 0; for ( uint32_t k = 0; k < 256u; ++k ) { const uint32_t c = before0[k]; before0[k] = run; run += c; } total0 = run; }
+    __syncthreads();
+    uint32_t at0 = before0[t], at1 = total0 + ( lo - before0[t] );
+    for ( uint32_t i = lo; i < hi; ++i ) {
+        const uint32_t v = cls[i] == 0u ? at0++ : at1++;
+        order[v] = i; order[n + i] = v;
+    }
+}
+#ifndef TERRA_JOB_ORDER_MIN_BLOCKS
+#define TERRA_JOB_ORDER_MIN_BLOCKS 256
+#endif
+size_t terra_block_order_bytes ( const DevRenderParams& p, bool small_too ) {          // class word + the two halves of the order per pixel block, or 0: this launch keeps the order of the numbering
+    if ( terra_job_streams_bytes ( p ) == 0 || p.scene.n_tris == 0 || p.scene.n_tris > 4096 ) return 0;
+    const size_t blocks = terra_render_blocks ( p );
+    // (not for small launches -- below TERRA_JOB_ORDER_MIN_BLOCKS pixel blocks, a 256 x 256 rectangle: a tile-sized call is one of several in flight, whose work hides its tail,
+    //  and its two extra small kernels would queue behind the other callers' render grids: the reference client's tile loop 66.5 -> 72.6 ms with them)
+    return blocks >= ( small_too ? 1u : ( unsigned ) TERRA_JOB_ORDER_MIN_BLOCKS ) ? ( blocks * 3 * sizeof ( uint32_t ) + 255 ) & ~size_t ( 255 ) : 0;
+}
+hipError_t terra_launch_block_order ( const DevRenderParams& p, uint32_t* cls, hipStream_t stream ) {      // p.block_order = cls + blocks
+    const uint32_t blocks = terra_render_blocks ( p );
+    if ( !p.block_order || !cls || blocks == 0 ) return hipErrorInvalidValue;
+    hipLaunchKernelGGL ( terra_block_class_kernel, dim3 ( ( blocks + 255 ) / 256 ), dim3 ( 256 ), 0, stream, p, blocks, cls );
+    hipLaunchKernelGGL ( terra_block_order_kernel, dim3 ( 1 ), dim3 ( 256 ), 0, stream, blocks, ( const uint32_t* ) cls, const_cast<uint32_t*> ( p.block_order ) );
+    return hipGetLastError();
 }
 hipError_t terra_launch_job_streams ( const DevRenderParams& p, hipStream_t stream ) {
     if ( terra_job_streams_bytes ( p ) == 0 ) return hipSuccess;

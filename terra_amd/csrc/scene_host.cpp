@@ -324,6 +324,7 @@ struct Scene {
     bool work_counters = false;         // terra_amd_set_work_counters: the render kernels count rays / nodes / tests / hits / draws (instrumentation, off by default)
     bool env_sampling = false;          // terra_amd_set_environment_sampling: Direct / Direct+MIS sample a lat-long environment through a TerraDistribution2D (built at commit)
     float* d_env_dist = nullptr;        // its tables on the device (own allocation)
+    int job_order = 1;                  // terra_amd_set_job_order (0 off, 1 on, 2 on for launches of any size): launches that key their streams ahead hand out the pixel blocks no camera ray hits last (launch_render)
     bool sampler_integration = false;   // terra_amd_set_sampler_integration: the pixel's Halton / stratified sampler feeds the first bounce (a launch parameter)
     int fast_max_stack = 1; uint32_t fast_nodes = 0;
     std::string commit_error;
@@ -437,6 +438,11 @@ extern "C" int terra_amd_set_environment_sampling ( HTerraScene h, int on ) {
     return 0;
 }
 extern "C" int terra_amd_get_environment_sampling ( HTerraScene h ) { return S ( h )->env_sampling ? 1 : 0; }
+extern "C" int terra_amd_set_job_order ( HTerraScene h, int on ) {
+    if ( on < 0 || on > 2 ) return fail ( kTerraAmdErrBadArgument, "terra_amd_set_job_order: 0 (off), 1 (on) or 2 (on for launches of any size)" );
+    S ( h )->job_order = on; return 0;
+}
+extern "C" int terra_amd_get_job_order ( HTerraScene h ) { return S ( h )->job_order; }
 extern "C" int terra_amd_set_sampler_integration ( HTerraScene h, int on ) { S ( h )->sampler_integration = on != 0; return 0; }
 extern "C" int terra_amd_get_sampler_integration ( HTerraScene h ) { return S ( h )->sampler_integration ? 1 : 0; }
 extern "C" void terra_amd_set_frame_seed ( HTerraScene h, uint64_t seed ) { S ( h )->frame_seed = seed; }
@@ -1360,7 +1366,8 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     const size_t stream_bytes = terra_job_streams_bytes ( p );
     if ( stream_bytes && ( p.fb_w > 65535u || p.fb_h > 65535u ) ) return fail ( kTerraAmdErrBadArgument, "framebuffer of %u x %u: at most 65,535 pixels per side (the job table packs a pixel into 32 bits)", p.fb_w, p.fb_h );
     const size_t spill_bytes = terra_fast_spill_bytes ( p );                 // fast-tree launches: the part of the lanes' traversal stacks that does not live in LDS
-    const size_t scratch_bytes = header + partial_bytes + stream_bytes + spill_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)][stack spill (fast tree)]
+    const size_t order_bytes = s->job_order ? terra_block_order_bytes ( p, s->job_order == 2 ) : 0;           // LDS-resident launches: the order the pixel blocks are handed out in (render_kernels.hip "job order")
+    const size_t scratch_bytes = header + partial_bytes + stream_bytes + spill_bytes + order_bytes;      // [queue word][job sums][job streams (LDS-resident scenes)][stack spill (fast tree)][job order]
     // (a thread's slot keeps scratch for tile-sized calls only: a full-frame call's gigabytes come from, and go back to, the device's pool)
     // a launch's scratch is bounded: 48 bytes per (pixel, lane-per-pixel) job on LDS-resident scenes -- a 4K frame at 64 lanes per pixel asks for 25 GB per concurrent stream.
     // Beyond TERRA_SCRATCH_MAX_GB the call is refused with the size in the message (fewer lanes per pixel, or the frame in several calls, give the same framebuffer)
@@ -1378,6 +1385,8 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
     p.job_blocks = blocks * split; p.job_queue = terra_render_wants_queue ( p ) ? ( uint32_t* ) scratch : nullptr;
     p.job_streams = stream_bytes ? ( uint4* ) ( ( char* ) scratch + header + partial_bytes ) : nullptr;
     p.stack_spill = spill_bytes ? ( uint32_t* ) ( ( char* ) scratch + header + partial_bytes + stream_bytes ) : nullptr;
+    uint32_t* const order_cls = order_bytes ? ( uint32_t* ) ( ( char* ) scratch + header + partial_bytes + stream_bytes + spill_bytes ) : nullptr;
+    p.block_order = order_cls ? order_cls + blocks : nullptr;
     {   // the job decode divides block numbers by launch constants: as multiplications by ceil(2^32 / d), exact while (largest dividend) * divisor < 2^32
         const uint64_t bpt = p.tile_size / 16, bpt2 = bpt * bpt, tiles_x = ( p.w + p.tile_size - 1 ) / p.tile_size, tiles_y = ( p.h + p.tile_size - 1 ) / p.tile_size;
         auto magic = [] ( uint64_t d ) { return d <= 1 ? 0u : ( uint32_t ) ( ( ( 1ull << 32 ) + d - 1 ) / d ); };
@@ -1391,6 +1400,7 @@ static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, Thr
         if ( pooled ) ( void ) hipFreeAsync ( scratch, stream );
         return fail ( kTerraAmdErrUnsupported, "the traversal stack of this scene's tree (%u entries) needs %zu KB of LDS per block, more than the %zu KB a block can have", p.stack_depth, terra_lds_bytes ( p ) / 1024, terra_lds_block_limit() / 1024 );
     }
+    if ( e == hipSuccess && order_cls ) e = terra_launch_block_order ( p, order_cls, stream );
     if ( e == hipSuccess ) e = terra_launch_job_streams ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_render ( p, stream );
     if ( e == hipSuccess ) e = terra_launch_resolve ( p, stream );

@@ -90,6 +90,8 @@ _EXTRA = {
     "terra_amd_traversal_info": (C.c_int, [C.c_void_p, C.POINTER(TraversalInfo)]),
     "terra_amd_set_tree_builder": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_tree_builder": (C.c_int, [C.c_void_p]),
+    "terra_amd_set_job_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "terra_amd_get_job_order": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sample_split": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_sample_split": (C.c_int, [C.c_void_p]),
     "terra_amd_set_environment_lighting": (C.c_int, [C.c_void_p, C.c_int]),

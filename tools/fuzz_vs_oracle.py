@@ -75,6 +75,8 @@ for it in range(n_iter):
         lib.clear_error()
         # (work counters on or off at random: the counting kernels are separate instantiations, and only the ones WITHOUT counters take the light-sample rays' shortcut)
         s = scenes.build_scene(lib, d, tree_mode=tree, counters=bool(rs.randint(2))); runtime.check(lib.set_sample_split(s, split))
+        if hasattr(lib, "set_job_order"):      # the order LDS-resident launches hand their pixel blocks out in: off, the default (off at these frame sizes), or on for launches of any size
+            runtime.check(lib.set_job_order(s, int(rs.choice([0, 1, 2, 2]))))
         if tree and hasattr(lib, "debug_fast_stack_lds"):      # the fast tree's stack: sometimes only 1-3 entries in LDS, so that the HBM part is exercised (the image must not change)
             runtime.check(lib.debug_fast_stack_lds(s, int(rs.choice([0, 0, 1, 2, 3]))))
         fb = runtime.DeviceFramebuffer(W, H)

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--max-devices", type=int, default=8)
     ap.add_argument("--sample-split", type=int, default=32)
+    ap.add_argument("--job-order", type=int, default=-1, help="terra_amd_set_job_order (A/B; -1: the library's default)")
     a = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401  first: the library binds to the HIP runtime torch loads
@@ -45,6 +46,8 @@ def main():
         if runtime.last_error():
             out["runs"].append({"devices": n, "error": runtime.last_error()}); break
         runtime.check(lib.set_sample_split(scene, a.sample_split))
+        if a.job_order >= 0:
+            runtime.check(lib.set_job_order(scene, a.job_order))
         fb = api.Framebuffer(lib, d.width, d.height); cam = scenes.camera_of(d)
         rc = lib.render_multi(C.byref(cam), scene, C.byref(fb.fb), 0, 0, d.width, d.height, 64)          # warm-up: replicas' first launch, communicator, staging buffers
         if rc != 0:
