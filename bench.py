@@ -17,8 +17,9 @@ per GPU) the frame's 64x64 tiles are dealt round-robin to the ranks (t % N == ra
 scene replica, and ONE gather (RCCL over xGMI; terra_amd.runtime.gather_frame, the function the gloo test covers) moves the
 packed tiles to rank 0, which unpacks them into the full frame. Pack, gather and unpack run on a second stream: the next
 step's render (disjoint tiles) starts as soon as the pack has read the rank's own tiles. Total work is fixed as N grows:
-"scaling": "strong". value = frame samples * K / max-over-ranks wall time. Every rank count renders with the same sample split
-(terra_amd_set_sample_split, default 32 lanes per pixel: the frame of 32 successive 16-spp calls), so the image does not
+"scaling": "strong". value = frame samples * K / max-over-ranks wall time. Every rank count renders with the library's AUTOMATIC sample split
+for a launch of its size (terra_amd_auto_sample_split: 8 / 16 / 32 / 32 lanes per pixel at 1 / 2 / 4 / 8 ranks on the headline frame -- the frame of that many
+successive calls of spp / split samples; --sample-split S fixes it for every N), so the image does not
 depend on N and a 1/8 share of the frame still fills a GPU.
 
 Also on the JSON line (rank 0):
@@ -59,10 +60,11 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2      # 256 CUs x 4 SIMD-32, a wave64 VALU instr
 TA_PEAK_GCYC = 256 * 2.4              # one texture addresser per CU, 2.4 GHz: G addresser-cycles per second
 L2_GATHER_GBS = 18800.0               # MI355X_MICROARCH.md "Indexed rows": rows gathered from the XCDs' L2, 16.8-18.8 TB/s chip-wide (the upper figure: the replica kernel moves 17.5)
 TILE = 64
-# Sample split of the timed launches (terra_amd_set_sample_split): the frame equals that of this many successive calls of spp/split samples. With the job queue a
-# launch wants many jobs per resident lane -- at N = 8 a rank renders an eighth of the frame -- and short jobs at its end (Cornell 512 spp: split 8 / 16 / 32 / 64
-# -> 58.6 / 57.2 / 56.7 / 60.6 ms, Direct 16 / 32 -> 112.0 / 108.9; slowest 1/8 share 9.04 / 8.44 / 8.34 / 8.25 ms; profiles/r03_measurements/shard_balance.log, ab_hall_split.log)
-DEFAULT_SPLIT = 32
+# Sample split of the timed launches (terra_amd_set_sample_split): the frame equals that of this many successive calls of spp/split samples. 0 = the library's automatic choice
+# for a launch of this size (terra_amd_auto_sample_split; measure() resolves it to a number so that the sharded and the unsharded frames of a run share it and the line reports
+# it): with the job order of round 4 a launch of an LDS-resident scene wants ~50 jobs per resident lane, the others ~200 -- slowest of 1 / 2 / 4 / 8 shards of the Cornell frame
+# 50.2 / 25.6 / 13.5 / 7.0 ms at the automatic 8 / 16 / 32 / 32 against 53.5 / 26.9 / 13.5 / 7.0 at 32 everywhere (profiles/r04_measurements/split_matrix.log)
+DEFAULT_SPLIT = 0
 TREE_MODES = {"auto": 2, "reference": 0, "fast": 1}
 INTEGRATORS = {"simple": 0, "direct": 1, "mis": 2}
 
@@ -82,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (the other configurations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal of N ranks on fewer GPUs: the gather goes through host memory)")
     ap.add_argument("--tree", default="auto", choices=list(TREE_MODES), help="terra_amd_set_tree_mode: auto (2, the library default: leaf-box cull / fast tree when the scene passes the numeric containment check), reference (0: the reference's tree, every traversal decision reproduced), fast (1)")
-    ap.add_argument("--sample-split", type=int, default=DEFAULT_SPLIT, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); the same for every N so the image does not depend on N")
+    ap.add_argument("--sample-split", type=int, default=DEFAULT_SPLIT, help="terra_amd_set_sample_split: lanes per pixel (the frame equals that of this many successive calls of spp/split samples); 0 (default) = the library's automatic choice for the launch each rank makes (terra_amd_auto_sample_split), a number = the same for every N")
     ap.add_argument("--check", action="store_true", help="after timing: one low-spp sharded+gathered pass into a fresh frame must equal an unsharded pass bit for bit (rank 0); on by default when N > 1")
     ap.add_argument("--no-check", action="store_true", help="N > 1: skip that extra pass")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-started N-rank child may run before its process group is killed (a hung rendezvous must not hang the parent; well below the driver's own 1500 s limit, so that the ranks are gone before the driver kills this parent)")
@@ -470,10 +472,14 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
     commit_ms = scenes.LAST_COMMIT_MS                                                    # terra_scene_commit alone: host tree build(s) + flattening + upload (reported separately)
     if runtime.last_error():
         raise SystemExit("scene commit failed: " + runtime.last_error())
-    runtime.check(lib.set_sample_split(scene, split), "terra_amd_set_sample_split")
     if getattr(c, "job_order", -1) >= 0:
         runtime.check(lib.set_job_order(scene, c.job_order), "terra_amd_set_job_order")
     ti = runtime.TraversalInfo(); runtime.check(lib.traversal_info(scene, C.byref(ti)))
+    if split == 0:          # the library's automatic choice for THIS rank count's launches, as a number: every launch of the run (timed, counted, checked) then uses the same chunks
+        split = lib.auto_sample_split(d.width, d.height, TILE, world, d.spp, int(bool(ti.lds_resident) and getattr(c, "job_order", -1) != 0))
+        if split < 1:
+            raise SystemExit("terra_amd_auto_sample_split: " + runtime.last_error())
+    runtime.check(lib.set_sample_split(scene, split), "terra_amd_set_sample_split")
     info = runtime.SceneInfo(); runtime.check(lib.scene_info(scene, C.byref(info)))
     cam = scenes.camera_of(d)
     W, H = d.width, d.height
@@ -599,7 +605,7 @@ def measure(c, d, tree, split, steps, warmup, check=False, prewarm_rect=None):
         fence()
         lib.scene_destroy(scene2)
     ti2 = runtime.TraversalInfo(); runtime.check(lib.traversal_info(scene, C.byref(ti2)))      # after the launches: what the last call actually ran
-    out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "check": ok, "phases": phases, "commit_ms": commit_ms,
+    out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "check": ok, "phases": phases, "commit_ms": commit_ms, "split": split,
            "per_launch": {k: v // launches for k, v in st.items() if k != "launches"},
            "traversal": {"fast_tree": bool(ti.fast_tree), "leaf_cull": bool(ti.leaf_cull), "note": ti.note.decode(), "last_call": getattr(ti2, "last_call", None)},
            "lds_resident": bool(ti.lds_resident),
@@ -704,10 +710,10 @@ def multi_device_block(workload_name, limit_s=300.0):
 EXTRA_WORKLOADS = [
     # (workload, tree, integrator, split, steps, warmup, prewarm rectangle, CPU seconds)
     # (sample split: with the job queue a launch wants >= ~20 jobs per resident lane, or its last jobs ramp down alone: hall 256 spp split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms)
-    ("hall_1080p_256spp", "auto", "simple", DEFAULT_SPLIT, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
-    ("hall_1080p_256spp", "reference", "simple", DEFAULT_SPLIT, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (5 s per step)
+    ("hall_1080p_256spp", "auto", "simple", 32, 2, 1, None, 8.0),                       # configs[2] on the default (automatic) path: fast tree
+    ("hall_1080p_256spp", "reference", "simple", 32, 1, 0, (896, 476, 128, 128), 0.0),  # ... and the reference's own tree, replica traversal (5 s per step)
     ("hall_x100_1080p_64spp", "auto", "simple", 4, 2, 1, None, 6.0),                   # the hall outside the coordinate range: fast tree + reachability replay
-    ("spheres_1080p_1024spp", "auto", "simple", DEFAULT_SPLIT, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
+    ("spheres_1080p_1024spp", "auto", "simple", 32, 1, 1, None, 8.0),                   # configs[3]: PARITY UNPINNED presets
     ("cornell_1080p_512spp_direct", "auto", "direct", DEFAULT_SPLIT, 3, 1, None, 8.0),             # configs[1] with the reference client's default integrator
     ("hall_1080p_64spp_direct", "auto", "direct", 8, 2, 1, None, 6.0),                             # configs[2]'s scene with that integrator (64 spp)
 ]
@@ -734,7 +740,7 @@ def main():
     m = measure(c, d, args.tree, args.sample_split, args.steps, args.warmup, check=args.check or (world > 1 and not args.no_check))
 
     if rank == 0:
-        blk = result_block(d, args.workload, args.tree, args.sample_split, args.steps, args.warmup, world, m, args.spp, integ_name)
+        blk = result_block(d, args.workload, args.tree, m["split"], args.steps, args.warmup, world, m, args.spp, integ_name)
         out = {"metric": "Msamples/s", "value": blk["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": blk["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": blk["config"]}
@@ -750,7 +756,7 @@ def main():
         if m.get("phases"):
             out["phases"] = m["phases"]
         if world == 1 and not c.dist_on and not args.no_host_api:
-            out["host_api"] = host_api(c, d, args.tree, args.sample_split, max(1, min(args.steps, 3)))
+            out["host_api"] = host_api(c, d, args.tree, m["split"], max(1, min(args.steps, 3)))
             # SURVEY.md 8(d)'s own definition of the metric -- wall time of terra_render(), kernel + the tile's D2H included -- as a top-level key beside `value`
             # (which is the device-resident rate the bench contract asks for)
             out["value_terra_render"] = out["host_api"]["full_frame_call"]["value"]
@@ -763,7 +769,7 @@ def main():
             for name, tree, integ, split, steps, warmup, prewarm, cpu_s in EXTRA_WORKLOADS:
                 dw = workload(name)
                 mw = measure(c, dw, tree, split, steps, warmup, prewarm_rect=prewarm)
-                b = result_block(dw, name, tree, split, steps, warmup, 1, mw, 0, integ)
+                b = result_block(dw, name, tree, mw["split"], steps, warmup, 1, mw, 0, integ)
                 if name.startswith("spheres"):
                     b["parity"] = "unpinned: the GGX and glass presets are this repo's definitions (the reference's are dead code, src/TerraPresets.c:298-465)"
                 if not args.no_cpu_baseline:          # the CPU renders the scene, not the tree mode: one measurement per workload

@@ -180,12 +180,18 @@ int  terra_amd_debug_fast_stack_lds ( HTerraScene scene, int entries );
    src/Terra.c:551-572). It exists for small tiles and shards: one GPU has more lanes than a 1/8 share
    of a 1080p frame has pixels. If spp is not a multiple of S the largest power of two dividing it is
    used. split = 0 picks S per call from the call's own size (about 200 jobs per lane the
-   GPU holds at once, chunks of at least 16 samples, at most 32 lanes per pixel: 32 for a 1080p frame or a 128-pixel tile at 512 spp, 8 at 128 spp): for clients that
+   GPU holds at once -- about 50 for the launches that use the job order, below --, chunks of at least 16 samples, at most 32 lanes per pixel: 32 for a 128-pixel tile
+   or a 1/8 shard of a 1080p frame at 512 spp, 8 for the whole frame of a small scene): for clients that
    render in small tiles, as the reference's does (satellite/include/Config.hpp:25), and for whole frames alike -- the render grid
    is persistent and hands (pixel, chunk) jobs to its lanes from a queue, and a launch with few jobs per lane ends with its last jobs
    ramping down alone. A launch parameter: no commit needed. */
 int  terra_amd_set_sample_split ( HTerraScene scene, int split );
 int  terra_amd_get_sample_split ( HTerraScene scene );
+/* What split = 0 chooses for rank 0's share (tiles t with t % world == 0; world = 1: the whole rectangle) of a width x height rectangle at spp samples per pixel:
+   job_ordered = 1 for scenes whose launches use the job order (TerraAmdTraversalInfo::lds_resident scenes with terra_amd_set_job_order on, rectangles of at least
+   256 pixel blocks) -- they end on short jobs and want about 50 jobs per resident lane --, 0 for the others, which want about 200. For clients that must know the
+   chunking of a call (bench.py renders its sharded and unsharded frames with the same number so that they can be compared bit for bit). -1 on bad arguments. */
+int  terra_amd_auto_sample_split ( size_t width, size_t height, size_t tile, int world, size_t spp, int job_ordered );
 
 /* Job order, on by default. A render launch on a scene that is staged whole in the compute units' local memory hands its (pixel, chunk) jobs to the lanes of a persistent
    grid, and ends when the longest of the jobs in flight at the end is done: about a millisecond on a Cornell-box frame whatever the launch's share of it -- a seventh of the

@@ -6,6 +6,7 @@
 hipError_t terra_launch_render ( const DevRenderParams& p, hipStream_t stream );
 hipError_t terra_launch_job_streams ( const DevRenderParams& p, hipStream_t stream );      // before terra_launch_render: DevRenderParams::job_streams
 size_t terra_block_order_bytes ( const DevRenderParams& p, bool small_too );        // scratch of the job order (class + order words per pixel block); 0: the launch keeps the order of the numbering (p.job_blocks, p.lds_mode set); small_too: also below TERRA_JOB_ORDER_MIN_BLOCKS
+uint32_t   terra_job_order_min_blocks ( void );                     // launches of fewer pixel blocks keep the numbering's order (unless terra_amd_set_job_order(scene, 2))
 hipError_t terra_launch_block_order ( const DevRenderParams& p, uint32_t* cls, hipStream_t stream );      // before terra_launch_job_streams: fills p.block_order (= cls + blocks)
 size_t terra_job_streams_bytes ( const DevRenderParams& p );        // 0: this launch keys its streams in the render kernel (p.lds_mode, p.job_blocks set)
 // (render_kernels.hip is compiled as several translation units, one per template MODE: 0 reference tree from global memory, 1 LDS-resident, 2 fast tree, 3 fast tree + reachability replay)

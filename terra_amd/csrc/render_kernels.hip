@@ -429,8 +429,11 @@ TD void job_next ( const DevRenderParams& p, float* aux, Jobs& j, PixelStreams& 
     int prior_samples;
     if constexpr ( TERRA_JOB_STREAM_TABLE && TABLE ) {
         const uint4 e1 = p.job_streams[2 * ( size_t ) job + 1];       // keyed by terra_job_streams_kernel (below): the job's pixel comes with it, the decode's divisions are not repeated here
-        if ( e1.z == 0xffffffffu ) return;                                 // (a pixel outside the rectangle)
         const uint4 e0 = p.job_streams[2 * ( size_t ) job];
+        // both halves of the entry are asked for BEFORE the first is looked at: the compiler otherwise fetches e1.z, waits, branches, and only then fetches the rest -- two
+        // memory round trips per job switch with the whole wave parked at the wait (Cornell 512 spp, split 32: TERRA_JOB_ENTRY_ONE_TRIP 0 / 1, profiles/r04_measurements/ab_job_entry.log)
+        asm volatile ( "" : : "v" ( e0.x ), "v" ( e0.y ), "v" ( e0.z ), "v" ( e0.w ), "v" ( e1.x ), "v" ( e1.y ), "v" ( e1.z ), "v" ( e1.w ) );
+        if ( e1.z == 0xffffffffu ) return;                                 // (a pixel outside the rectangle)
         j.px = e1.z & 0xffffu; j.py = e1.z >> 16;
         chunk = ( job >> 8 ) & ( p.split - 1 );
         rs.a.state = ( uint64_t ) e0.x | ( ( uint64_t ) e0.y << 32 ); rs.a.inc = 1;
@@ -993,6 +996,7 @@ __global__ __launch_bounds__ ( 256 ) void terra_block_order_kernel ( uint32_t n,
 #ifndef TERRA_JOB_ORDER_MIN_BLOCKS
 #define TERRA_JOB_ORDER_MIN_BLOCKS 256
 #endif
+uint32_t terra_job_order_min_blocks ( void ) { return TERRA_JOB_ORDER_MIN_BLOCKS; }
 size_t terra_block_order_bytes ( const DevRenderParams& p, bool small_too ) {          // class word + the two halves of the order per pixel block, or 0: this launch keeps the order of the numbering
     if ( terra_job_streams_bytes ( p ) == 0 || p.scene.n_tris == 0 || p.scene.n_tris > 4096 ) return 0;
     const size_t blocks = terra_render_blocks ( p );

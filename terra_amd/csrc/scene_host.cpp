@@ -424,6 +424,15 @@ extern "C" int terra_amd_set_sample_split ( HTerraScene h, int split ) {
     return 0;
 }
 extern "C" int terra_amd_get_sample_split ( HTerraScene h ) { return ( int ) S ( h )->sample_split; }
+static uint32_t auto_sample_split ( uint32_t blocks, uint32_t spp, bool ordered );
+extern "C" int terra_amd_auto_sample_split ( size_t width, size_t height, size_t tile, int world, size_t spp, int job_ordered ) {
+    if ( width == 0 || height == 0 || tile < 16 || tile % 16 || world < 1 || spp == 0 ) return fail ( kTerraAmdErrBadArgument, "terra_amd_auto_sample_split: empty rectangle, tile not a multiple of 16, or no rank" ) , -1;
+    const uint64_t tiles = ( ( width + tile - 1 ) / tile ) * ( ( height + tile - 1 ) / tile ), own = ( tiles + ( uint64_t ) world - 1 ) / ( uint64_t ) world, bpt = tile / 16;
+    const uint32_t blocks = ( uint32_t ) ( own * bpt * bpt );
+    uint32_t split = auto_sample_split ( blocks, ( uint32_t ) spp, job_ordered != 0 && blocks >= terra_job_order_min_blocks() );
+    while ( split > 1 && spp % split ) split >>= 1;
+    return ( int ) split;
+}
 extern "C" int terra_amd_set_environment_lighting ( HTerraScene h, int on ) {
     Scene* s = S ( h );
     if ( s->env_lighting != ( on != 0 ) ) { s->env_lighting = on != 0; s->dirty_lights = true; s->committed = false; }
@@ -1338,19 +1347,27 @@ static void account_launch ( Scene* s, const DevRenderParams& p ) {
 // sums into the pixels in chunk order and tonemaps (DevRenderParams::split; split == 1: one chunk per pixel).
 struct ThreadSlot;
 static void* slot_scratch ( ThreadSlot* slot, size_t bytes );
+// The automatic sample split (terra_amd_set_sample_split(scene, 0); terra_amd_auto_sample_split): a function of the launch's size -- its 16x16 pixel blocks --, its spp and
+// whether its jobs are handed out in the job order, so the same calls always give the same framebuffer. Chunks of at least 16 samples, at most 32 lanes per pixel (the
+// reference client's 128-pixel tiles at 512 spp, called from 8 threads, 69.1 -> 66.7 ms per frame with 32 instead of 16).
+//   * launches WITHOUT the job order end with their last jobs ramping down alone, so they want many short jobs: about 200 per lane the GPU holds at once (256 CUs x 5 blocks x
+//     256 lanes) -- hall 1080p 256 spp: split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms (profiles/r03_measurements/ab_job_queue.log);
+//   * launches WITH it (LDS-resident scenes, render_kernels.hip "job order") end on short jobs whatever the split, and every job switch costs them (its code runs for one
+//     or two lanes of a wave; the jobs' stream table and sums are traffic): about 50 jobs per lane is where the slowest of N shards of the Cornell frame is fastest --
+//     split 8 / 16 / 32 / 32 for 1 / 2 / 4 / 8 shards: 50.2 / 25.6 / 13.5 / 7.0 ms, against 53.5 / 26.9 / 13.5 / 7.0 at 32 everywhere
+//     (tools/split_matrix.py, profiles/r04_measurements/split_matrix.log).
+static uint32_t auto_sample_split ( uint32_t blocks, uint32_t spp, bool ordered ) {
+    const uint64_t enough = ordered ? 61440u : 245760u;          // blocks x split: x 256 jobs each, over 327,680 resident lanes = 48 / 192 jobs per lane
+    uint32_t split = 1;
+    while ( split < 32 && ( uint64_t ) blocks * split < enough && spp / ( split * 2 ) >= 16 ) split *= 2;
+    return split;
+}
 static int launch_render ( Scene* s, DevRenderParams& p, hipStream_t stream, ThreadSlot* slot = nullptr, int device = -1 ) {      // device: the (current) device of the launch, -1 = the scene's primary
     uint32_t split = s->sample_split;
     const uint32_t blocks = terra_render_blocks ( p );
     if ( blocks == 0 ) return 0;
-    if ( split == 0 ) {
-        // automatic: about 200 jobs per lane the GPU holds at once (256 CUs x 5 blocks x 256 lanes), chunks of at least 16 samples, at most 32 lanes per pixel (Cornell 1080p
-        // 512 spp: 8 / 16 / 32 / 64 lanes per pixel -> 57.5 / 55.8 / 55.1 / 59.8 ms; profiles/r03_measurements/ab_job_queue.log). A launch whose lanes get only
-        // a handful of jobs each ends with its last jobs ramping down alone (hall 1080p 256 spp: split 1 / 4 / 8 -> 276.6 / 255.1 / 251.0 ms); a small tile wants
-        // the split to fill the GPU at all. Depends only on the call's rectangle, shard and spp, so the same calls always give the same framebuffer.
-        split = 1;
-        // (up to 32 lanes per pixel: the reference client's 128-pixel tiles at 512 spp, called from 8 threads, 69.1 -> 66.7 ms per frame with 32 instead of 16)
-        while ( split < 32 && ( uint64_t ) blocks * split < 245760 && p.spp / ( split * 2 ) >= 16 ) split *= 2;
-    }
+    p.job_blocks = blocks;                                            // (what terra_block_order_bytes looks at is the launch's size and layout, not the split)
+    if ( split == 0 ) split = auto_sample_split ( blocks, p.spp, s->job_order && terra_block_order_bytes ( p, s->job_order == 2 ) != 0 );
     while ( split > 1 && p.spp % split ) split >>= 1;              // chunks must be equal: fall back to the largest power of two dividing spp
     if ( split < 1 ) split = 1;
     if ( device < 0 ) device = s->device;

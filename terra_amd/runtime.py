@@ -94,6 +94,7 @@ _EXTRA = {
     "terra_amd_get_job_order": (C.c_int, [C.c_void_p]),
     "terra_amd_set_sample_split": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_sample_split": (C.c_int, [C.c_void_p]),
+    "terra_amd_auto_sample_split": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_int]),
     "terra_amd_set_environment_lighting": (C.c_int, [C.c_void_p, C.c_int]),
     "terra_amd_get_environment_lighting": (C.c_int, [C.c_void_p]),
     "terra_amd_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),

@@ -140,6 +140,6 @@ def test_roofline_block_is_recomputable_from_the_committed_pmc_summary():
         assert mix and 0.4 < mix["frac_of_peak"] < 1.0 and r["valu_frac_of_mix_ceiling"] < 1.1, (key, mix)
         if "fast tree" in rec["traversal"]:                               # the global-memory kernels carry the gather evidence
             assert 0 < r["ta_busy_frac"] <= 1.02 and 0 < r["wave_wait_frac"] < 1 and 0 < r["l2_gather"]["frac"] < 1.2
-    hk = bench.pmc_key("cornell_1080p_512spp", "auto", "simple", bench.DEFAULT_SPLIT, 0)          # the headline launch's record
+    hk = bench.pmc_key("cornell_1080p_512spp", "auto", "simple", 8, 0)          # the headline launch's record (bench.DEFAULT_SPLIT = 0 resolves to 8 lanes per pixel for that frame on one GPU)
     head = bench.roofline(hk, pmc[hk]["counters_per_launch"], pmc[hk]["kernel_ms"], True, 1)
     assert head["bound"] == "valu" and 0.6 < head["frac"] < 0.8 and head["pmc_file"] == "profiles/" + f.name

@@ -5,8 +5,8 @@ a crop of the finished frame against the oracle (bit-exact: sums, tonemapped pix
 where the launch reports them), and size-independent properties of the whole frame (sample counts, determinism of the
 shard -> pack -> unpack path, counter identities).
 
-  configs[1]  Cornell box 1920x1080, 512 spp, 8 bounces -- the exact bench.py launch: its sample split (bench.DEFAULT_SPLIT = 32), i.e. the
-              framebuffer of 32 successive calls of 16 spp (reference src/Terra.c:551-572: a call sums its samples from
+  configs[1]  Cornell box 1920x1080, 512 spp, 8 bounces -- the exact bench.py launch: its sample split (bench.DEFAULT_SPLIT = 0 = the library's automatic choice, 8 for this
+              frame), i.e. the framebuffer of 8 successive calls of 64 spp (reference src/Terra.c:551-572: a call sums its samples from
               zero, adds them to the running sum and re-tonemaps)
   configs[2]  ~100k-triangle hall 1920x1080, 256 spp: automatic (what bench.py times), replica and forced fast tree;
               plus the hall x 100 (outside the containment range: reachability mode) at bench.py's 1080p / 64 spp
@@ -28,7 +28,8 @@ pytestmark = pytest.mark.gpu
 import bench  # noqa: E402  (nothing GPU-related at module level)
 
 TILE = 64       # bench.py's tile size
-SPLIT = bench.DEFAULT_SPLIT     # the sample split of bench.py's timed launches (32: the framebuffer of 32 successive calls of spp/32 samples)
+SPLIT = 32           # the sample split bench.py gives its hall / sphere-scene workloads (the framebuffer of 32 successive calls of spp/32 samples)
+HEADLINE_SPLIT = 8   # ... and what its default (0: the library's automatic split) resolves to for the headline frame on one GPU (checked below)
 THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 
 
@@ -89,24 +90,26 @@ def device_frame(L, d, split=1, tree_mode=None, calls=True, shard=None, counters
 
 
 def test_config2_headline_launch_cornell_1080p_512spp_bench_split(H, L, orc_lib, devmath_mode):
-    """the launch bench.py times: 1920x1080, 512 spp, its sample split (bench.DEFAULT_SPLIT = 32: == 32 reference calls of 16 spp), library defaults"""
+    """the launch bench.py times: 1920x1080, 512 spp, its sample split (bench.DEFAULT_SPLIT = 0 -> 8: == 8 reference calls of 64 spp), library defaults"""
     d = scenes.cornell_box(1920, 1080, 512, bounces=8)
-    got = device_frame(L, d, split=SPLIT, calls=False, counters=False)      # exactly bench.py's timed launch: library defaults -- automatic traversal, no work counters -- and its sample split
+    assert bench.DEFAULT_SPLIT == 0 and L.auto_sample_split(1920, 1080, TILE, 1, 512, 1) == HEADLINE_SPLIT          # what bench.py's measure() resolves its default to
+    assert [L.auto_sample_split(1920, 1080, TILE, n, 512, 1) for n in (2, 4, 8)] == [16, 32, 32] and L.auto_sample_split(1920, 1080, TILE, 1, 256, 0) == 16
+    got = device_frame(L, d, split=HEADLINE_SPLIT, calls=False, counters=False)      # exactly bench.py's timed launch: library defaults -- automatic traversal, no work counters -- and its sample split
     assert got["tree_mode"] == 2 and got["traversal"] == "reference tree + leaf-box cull"      # what BENCH's config.traversal names
     assert (got["samples"] == 512).all() and np.isfinite(got["pixels"]).all()
     assert got["stats"]["samples"] == 1920 * 1080 * 512 and got["stats"]["pixels"] == 1920 * 1080 and got["stats"]["rays"] == 0      # (host-kept totals; the device counters are off)
-    lean = device_frame(L, d, split=SPLIT, calls=False)           # bench.py's extra counting launch: the same frame, counters on
+    lean = device_frame(L, d, split=HEADLINE_SPLIT, calls=False)           # bench.py's extra counting launch: the same frame, counters on
     assert H.same_bits(lean["acc"], got["acc"]) and H.same_bits(lean["pixels"], got["pixels"])
     s = lean["stats"]
     assert s["samples"] == 1920 * 1080 * 512 and s["pixels"] == 1920 * 1080 and s["rand_calls"] == 4 * s["hits"] and s["rays"] > s["samples"]
-    counted = device_frame(L, d, split=SPLIT, calls=True)         # ... and with per-pixel stream-B draw counts
+    counted = device_frame(L, d, split=HEADLINE_SPLIT, calls=True)         # ... and with per-pixel stream-B draw counts
     assert H.same_bits(counted["acc"], got["acc"]) and H.same_bits(counted["pixels"], got["pixels"])
     assert int(counted["rand_calls"].astype(np.uint64).sum()) == s["rand_calls"]
     got["rand_calls"] = counted["rand_calls"]
     # two crops: inside the box (back wall), and the box's left border (background | red wall)
-    dch = scenes.cornell_box(1920, 1080, 512 // SPLIT, bounces=8)
+    dch = scenes.cornell_box(1920, 1080, 512 // HEADLINE_SPLIT, bounces=8)
     for rect in ((936, 300, 48, 32), (400, 520, 48, 32)):
-        want = H.Unit("orc").render_pixels(dch, passes=SPLIT, rect=rect, threads=THREADS, sum_calls=True)
+        want = H.Unit("orc").render_pixels(dch, passes=HEADLINE_SPLIT, rect=rect, threads=THREADS, sum_calls=True)
         assert (crop(want["samples"], rect) == 512).all()
         assert_crop_equals_oracle(H, got, want, rect)
     # the same frame without the split is a DIFFERENT (equally valid) frame: one call of 512 spp; its crop is the oracle's too
@@ -116,7 +119,7 @@ def test_config2_headline_launch_cornell_1080p_512spp_bench_split(H, L, orc_lib,
     assert_crop_equals_oracle(H, one, want1, rect)
     assert not H.same_bits(crop(one["acc"], rect), crop(got["acc"], rect))
     # the replica traversal (mode 0) renders the same split-8 frame, and is the mode whose work counters are the reference's
-    rep = device_frame(L, d, split=SPLIT, tree_mode=0, calls=False)
+    rep = device_frame(L, d, split=HEADLINE_SPLIT, tree_mode=0, calls=False)
     assert rep["traversal"] == "reference tree, replica traversal"
     assert H.same_bits(rep["acc"], got["acc"]) and H.same_bits(rep["pixels"], got["pixels"])
     # (the cull launch's fused box test may decide a grazing box differently from the replica: node counts agree to parts per million; hits are the image's)
