@@ -153,6 +153,20 @@ def test_shard_helpers(L):
     assert L.shard_tile_count(64, 64, 0, 0, 1) < 0
 
 
+def test_automatic_sample_split_rule(L):
+    # what terra_amd_set_sample_split(scene, 0) chooses (a pure function of the launch's size): launches that use the job order aim at ~50 jobs per resident lane ...
+    assert [L.auto_sample_split(1920, 1080, 64, n, 512, 1) for n in (1, 2, 4, 8, 16)] == [8, 16, 32, 32, 32]
+    # ... the others at ~200 (chunks of at least 16 samples, at most 32 lanes per pixel) ...
+    assert [L.auto_sample_split(1920, 1080, 64, n, 512, 0) for n in (1, 2, 8)] == [32, 32, 32] and L.auto_sample_split(1920, 1080, 64, 1, 256, 0) == 16
+    assert L.auto_sample_split(3840, 2160, 64, 1, 4096, 0) == 8 and L.auto_sample_split(1920, 1080, 64, 1, 16, 1) == 1 and L.auto_sample_split(1920, 1080, 64, 1, 48, 1) == 2
+    # ... a launch below the job order's size limit is not ordered whatever the flag says (a 128-pixel tile: 64 pixel blocks)
+    assert L.auto_sample_split(128, 128, 64, 1, 512, 1) == L.auto_sample_split(128, 128, 64, 1, 512, 0) == 32
+    # the split always divides spp
+    assert L.auto_sample_split(1920, 1080, 64, 1, 96, 0) == 4 and 96 % L.auto_sample_split(1920, 1080, 64, 1, 96, 1) == 0 and L.auto_sample_split(1920, 1080, 64, 1, 17 * 32, 0) == 32
+    assert L.auto_sample_split(0, 1080, 64, 1, 512, 1) < 0 and L.auto_sample_split(1920, 1080, 24, 1, 512, 1) < 0 and L.auto_sample_split(1920, 1080, 64, 0, 512, 1) < 0
+    L.clear_error()
+
+
 # ---------------------------------------------------------------------------
 # automatic traversal policy: the commit-time containment check (host only)
 # ---------------------------------------------------------------------------

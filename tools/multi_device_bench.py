@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--workload", default="cornell_1080p_512spp")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--max-devices", type=int, default=8)
-    ap.add_argument("--sample-split", type=int, default=32)
+    ap.add_argument("--sample-split", type=int, default=0, help="terra_amd_set_sample_split (0: the library's automatic choice per launch, as bench.py's default)")
     ap.add_argument("--job-order", type=int, default=-1, help="terra_amd_set_job_order (A/B; -1: the library's default)")
     a = ap.parse_args()
     import numpy as np
