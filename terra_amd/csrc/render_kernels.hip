@@ -953,27 +953,35 @@ __global__ __launch_bounds__ ( 256 ) void terra_job_streams_kernel ( DevRenderPa
 // every triangle, the test the traversal applies -- and hand the blocks out hit ones first, empty ones last: the long jobs are under way while there is still plenty of
 // short work to fill the lanes beside them, and the launch ends on jobs of a few ray iterations. Only the ORDER in which jobs are taken changes: which job a lane runs
 // never mattered (render_kernels.hip "jobs"), a block's sums are stored under its place in the order and the resolve kernel looks them up there (DevRenderParams::block_order).
+#define TERRA_CLASS_LDS_TRIS 256          // triangles the classifier stages in LDS (12 KB); larger scenes are read from global memory
 __global__ __launch_bounds__ ( 256 ) void terra_block_class_kernel ( DevRenderParams p, uint32_t nblocks, uint32_t* cls ) {
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if ( b >= nblocks ) return;
+    __shared__ float4 staged[3 * TERRA_CLASS_LDS_TRIS];
     const float4* tris = reinterpret_cast<const float4*> ( p.scene.tris );
-    const V3 cam_pos = v3p ( p.cam_pos );
+    if ( p.scene.n_tris <= TERRA_CLASS_LDS_TRIS ) {          // (every thread of the block takes part, also those beyond the last pixel block)
+        for ( uint32_t i = threadIdx.x; i < 3 * p.scene.n_tris; i += 256u ) staged[i] = tris[i];
+        __syncthreads();
+        tris = staged;
+    }
+    // eight lanes per pixel block, five of them with a probe each (centre and corners): the block's class is the vote of its lanes
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x, b = id >> 3, k = id & 7u;
     bool hit = false;
-    for ( uint32_t k = 0; k < 5 && !hit; ++k ) {
+    if ( b < nblocks && k < 5u ) {
         const uint32_t lx = k == 0 ? 8u : ( ( k - 1 ) & 1u ) * 15u, ly = k == 0 ? 8u : ( ( k - 1 ) >> 1 ) * 15u;
         const uint32_t tid = ( ( ( lx >> 3 ) | ( ( ly >> 3 ) << 1 ) ) << 6 ) | ( lx & 7u ) | ( ( ly & 7u ) << 3 );      // (block_pixel's thread -> pixel map, inverted)
         uint32_t px, py;
-        if ( !job_pixel_of_block ( p, b, tid, px, py ) ) continue;          // (a pixel outside the rectangle)
-        Ray r = make_ray ( cam_pos, camera_sample ( p, px, py, 0.5f, 0.5f ) );
-        r.o = r.o + r.d * 0.001f;
-        const RayState st = ray_state_init ( r );
-        for ( uint32_t t = 0; t < p.scene.n_tris && !hit; ++t ) {
-            const float4 a = tris[3 * t], bb = tris[3 * t + 1], cc = tris[3 * t + 2];
-            TriHit h;
-            hit = watertight ( r, st, v3 ( a.x, a.y, a.z ), v3 ( bb.x, bb.y, bb.z ), v3 ( cc.x, cc.y, cc.z ), h );
+        if ( job_pixel_of_block ( p, b, tid, px, py ) ) {                    // (else: a pixel outside the rectangle)
+            Ray r = make_ray ( v3p ( p.cam_pos ), camera_sample ( p, px, py, 0.5f, 0.5f ) );
+            r.o = r.o + r.d * 0.001f;
+            const RayState st = ray_state_init ( r );
+            for ( uint32_t t = 0; t < p.scene.n_tris && !hit; ++t ) {
+                const float4 a = tris[3 * t], bb = tris[3 * t + 1], cc = tris[3 * t + 2];
+                TriHit h;
+                hit = watertight ( r, st, v3 ( a.x, a.y, a.z ), v3 ( bb.x, bb.y, bb.z ), v3 ( cc.x, cc.y, cc.z ), h );
+            }
         }
     }
-    cls[b] = hit ? 0u : 1u;
+    const unsigned long long votes = __ballot ( hit );
+    if ( b < nblocks && k == 0 ) cls[b] = ( ( votes >> ( threadIdx.x & 56u ) ) & 0xffull ) ? 0u : 1u;
 }
 // order[0 .. n): the blocks of class 0 in their own order, then those of class 1; order[n + b]: block b's place. One block of 256 threads.
 __global__ __launch_bounds__ ( 256 ) void terra_block_order_kernel ( uint32_t n, const uint32_t* cls, uint32_t* order ) {
@@ -1007,7 +1015,7 @@ size_t terra_block_order_bytes ( const DevRenderParams& p, bool small_too ) {   
 hipError_t terra_launch_block_order ( const DevRenderParams& p, uint32_t* cls, hipStream_t stream ) {      // p.block_order = cls + blocks
     const uint32_t blocks = terra_render_blocks ( p );
     if ( !p.block_order || !cls || blocks == 0 ) return hipErrorInvalidValue;
-    hipLaunchKernelGGL ( terra_block_class_kernel, dim3 ( ( blocks + 255 ) / 256 ), dim3 ( 256 ), 0, stream, p, blocks, cls );
+    hipLaunchKernelGGL ( terra_block_class_kernel, dim3 ( ( blocks * 8 + 255 ) / 256 ), dim3 ( 256 ), 0, stream, p, blocks, cls );      // eight lanes per pixel block
     hipLaunchKernelGGL ( terra_block_order_kernel, dim3 ( 1 ), dim3 ( 256 ), 0, stream, blocks, ( const uint32_t* ) cls, const_cast<uint32_t*> ( p.block_order ) );
     return hipGetLastError();
 }
