@@ -212,9 +212,10 @@ def gather_frame(fb_pack, fb_unpack, width, height, tile, rank, world, dist, mak
     mark = mark or (lambda name: None)
     mine = fb_pack(rank)
     mark("packed")
-    if world == 1:
+    if world == 1 and not (dist is not None and dist.is_available() and dist.is_initialized()):
         mark("gathered"); mark("unpacked")
         return
+    # (one rank WITH a process group -- bench.py's TERRA_BENCH_DIST1 self-test -- still issues the collective: the gather of a group of one)
     n = packed_floats_per_rank(width, height, tile, world)
     assert mine.numel() == n
     if rank == dst:
