@@ -134,6 +134,12 @@ void build ( const TerraObject* objects, size_t nobj, std::vector<HostNode>& nod
 #ifndef TERRA_FAST_SAH_TRI_COST
 #define TERRA_FAST_SAH_TRI_COST 1.0f      // measured, not derived: hall / sphere scene render 81.4 / 65.5 ms at 1.0, 82.1 / 66.7 at 3.0 (profiles/r02_measurements/ab_fast_tree_loop.log)
 #endif
+#ifndef TERRA_FAST_BINS          // bins of the binned surface-area split (ranges above TERRA_FAST_SWEEP_MAX triangles)
+#define TERRA_FAST_BINS 32
+#endif
+#ifndef TERRA_FAST_SWEEP_MAX     // ranges of at most this many triangles are split by the exact sweep (0: bins all the way down)
+#define TERRA_FAST_SWEEP_MAX 1024
+#endif
 namespace fastbvh {
 
 static inline void grow ( TerraAABB& b, const TerraAABB& o ) {
@@ -195,9 +201,31 @@ Built build ( std::vector<Prim>& prims ) {
             mid = lo + best_k;
             return true;
         }
+        if ( cnt <= TERRA_FAST_SWEEP_MAX ) {
+            // a small range: the exact sweep over the three axes (every split position between two neighbours in centroid order) instead of the bins
+            std::vector<int> idx ( ( size_t ) cnt ); std::vector<float> ra ( ( size_t ) cnt );
+            float best_cost = FLT_MAX; int best_axis = -1, best_k = 0;
+            for ( int a = 0; a < 3; ++a ) {
+                for ( int i = 0; i < cnt; ++i ) idx[ ( size_t ) i] = lo + i;
+                std::sort ( idx.begin(), idx.end(), [&] ( int x, int y ) { return prims[x].c[a] < prims[y].c[a] || ( prims[x].c[a] == prims[y].c[a] && prims[x].soup < prims[y].soup ); } );
+                TerraAABB acc = empty();
+                for ( int i = cnt - 1; i > 0; --i ) { grow ( acc, prims[idx[ ( size_t ) i]].box ); ra[ ( size_t ) i] = half_area ( acc ); }
+                acc = empty();
+                for ( int k = 1; k < cnt; ++k ) {
+                    grow ( acc, prims[idx[ ( size_t ) k - 1]].box );
+                    const float cost = half_area ( acc ) * ( float ) k + ra[ ( size_t ) k] * ( float ) ( cnt - k );
+                    if ( cost < best_cost ) { best_cost = cost; best_axis = a; best_k = k; }
+                }
+            }
+            if ( best_axis < 0 ) { mid = lo + cnt / 2; return true; }
+            const int a = best_axis;
+            std::sort ( prims.begin() + lo, prims.begin() + hi, [&] ( const Prim & x, const Prim & y ) { return x.c[a] < y.c[a] || ( x.c[a] == y.c[a] && x.soup < y.soup ); } );
+            mid = lo + best_k;
+            return true;
+        }
         float cmin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, cmax[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
         for ( int i = lo; i < hi; ++i ) for ( int a = 0; a < 3; ++a ) { cmin[a] = std::min ( cmin[a], prims[i].c[a] ); cmax[a] = std::max ( cmax[a], prims[i].c[a] ); }
-        const int B = 16;
+        const int B = TERRA_FAST_BINS;
         float best_cost = FLT_MAX; int best_axis = -1, best_bin = -1;
         for ( int a = 0; a < 3; ++a ) {
             float ext = cmax[a] - cmin[a];
