@@ -100,3 +100,41 @@ def test_pack_layout_roundtrip():
     for rank in range(3):
         unpack_np(px2, res2, 32, rank, 3, pack_np(px, res, 32, rank, 3))
     assert np.array_equal(px, px2) and np.array_equal(res, res2)
+
+
+def _worker_one(rank, world, port, out_path):
+    """a process group of ONE (bench.py's TERRA_BENCH_DIST1 self-test): gather_frame must issue the collective, not return early"""
+    import torch
+    import torch.distributed as dist
+    from terra_amd import runtime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    real = dist.gather
+
+    class Counting:          # torch.distributed with gather counted
+        def __getattr__(self, name):
+            return getattr(dist, name)
+
+        def gather(self, *a, **k):
+            calls.append(1); return real(*a, **k)
+    n = runtime.packed_floats_per_rank(100, 70, 32, 1)
+    mine = torch.arange(n, dtype=torch.float32)
+    bufs = []
+    marks = []
+    runtime.gather_frame(fb_pack=lambda r: mine, fb_unpack=lambda src, buf: marks.append(("unpack", src)), width=100, height=70, tile=32, rank=0, world=1, dist=Counting(),
+                         make_buffer=lambda k: bufs.append(torch.zeros(k, dtype=torch.float32)) or bufs[-1], mark=marks.append)
+    ok = len(calls) == 1 and len(bufs) == 1 and torch.equal(bufs[0], mine) and marks == ["packed", "gathered", "unpacked"]      # rank 0's own tiles are never unpacked
+    # without a process group (dist = None): the early return, nothing gathered
+    marks2 = []
+    runtime.gather_frame(fb_pack=lambda r: mine, fb_unpack=None, width=100, height=70, tile=32, rank=0, world=1, dist=None, make_buffer=None, mark=marks2.append)
+    ok = ok and marks2 == ["packed", "gathered", "unpacked"]
+    open(out_path, "w").write("ok" if ok else f"calls={len(calls)} bufs={len(bufs)} marks={marks} marks2={marks2}")
+    dist.destroy_process_group()
+
+
+def test_group_of_one_still_issues_the_gather(tmp_path):
+    import torch.multiprocessing as mp
+    out = tmp_path / "one.txt"
+    mp.spawn(_worker_one, args=(1, _free_port(), str(out)), nprocs=1, join=True)
+    assert out.read_text() == "ok"
