@@ -38,15 +38,18 @@ struct DevNode {
 };
 static_assert ( sizeof ( DevNode ) == 64, "DevNode must be 64 bytes" );
 
-// A fast-tree node as the kernels read it (trace_device.h "MODE 2"), 64 bytes = four 16-byte loads, FOUR children: per child and axis the two planes of the child's
-// box as binary16 rounded outward (min down, max up), times DevScene's power-of-two scale -- p[child][axis] = min | max << 16 --, then the four child words (inner:
-// index of a wide node; leaf: DEV_CHILD_LEAF | (count - 1) << 27 | first triangle; DEV_CHILD_EMPTY with an inverted box -- min = +65504, max = -65504 -- for a
-// slot not in use). Made on the host from the builders' binary tree (tree_build.cpp fastbvh::widen).
+// A fast-tree node as the kernels read it (trace_device.h "MODE 2"), 128 bytes = one cache line, FOUR children: per child and axis the two planes of the child's box
+// as binary16 rounded outward (min down, max up), times DevScene's power-of-two scale, as one 32-bit word -- the four children's words of an axis side by side and
+// every such 16-byte group twice: q[axis][0][child] = min | max << 16 for rays travelling in the axis' positive direction, q[axis][1][child] = max | min << 16 for the
+// others, so that a ray LOADS the group whose low half is its near plane (no per-box swap) --, then the four child words (inner: index of a wide node; leaf:
+// DEV_CHILD_LEAF | (count - 1) << 27 | first triangle; DEV_CHILD_EMPTY with an inverted box -- min = +65504, max = -65504 -- for a slot not in use). A ray reads four
+// 16-byte pieces of a node (its three groups and the child words). Made on the host from the builders' binary tree (tree_build.cpp fastbvh::widen).
 struct DevFastNode {
-    uint32_t p[4][3];
+    uint32_t q[3][2][4];
     uint32_t child[4];
+    uint32_t pad[4];
 };
-static_assert ( sizeof ( DevFastNode ) == 64, "DevFastNode must be 64 bytes" );
+static_assert ( sizeof ( DevFastNode ) == 128, "DevFastNode must be 128 bytes" );
 
 struct DevTri {
     float    a[3]; uint32_t object;

@@ -1042,7 +1042,7 @@ static int upload_scene ( Scene* s ) {
             if ( s->tree_mode == 2 && auto_ok && resident ) s->tree_note = "containment verified: reference tree with the leaf-box cull (scene is LDS-resident)";
         } else HIP_TRY ( hipMemcpy ( base + o_fh, fwide.nodes.data(), fwide.nodes.size() * sizeof ( DevFastNode ), hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );
     }
-    if ( have_fast && s->fast_nodes >= ( 1u << 26 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address nodes by a 32-bit byte offset (at most 2^26 nodes)", s->fast_nodes );
+    if ( have_fast && s->fast_nodes >= ( 1u << 25 ) ) return fail ( kTerraAmdErrUnsupported, "fast tree of %u nodes: the kernels address the 128-byte nodes by a 32-bit byte offset (at most 2^25 nodes)", s->fast_nodes );
     for ( size_t k = 0; k < textures.size(); ++k ) {
         const TerraTexture* t = textures[k];
         HIP_TRY ( hipMemcpy ( base + tex_off[k], t->pixels, ( size_t ) t->width * t->height * t->components * t->depth, hipMemcpyHostToDevice ), kTerraAmdErrNoDevice );

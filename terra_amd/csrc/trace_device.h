@@ -497,15 +497,19 @@ TD Closest bvh_traverse ( const Tracer& T, const Ray& r, const RayState& st, Cou
 // (DevTri::pad of the fast soup). The triangle test itself is the same arithmetic.
 // Child word of a fast node: bit 31 leaf; leaf = (count-1) << 27 | first triangle.
 //
-// Node format in HBM (DevFastNode, 64 B, FOUR children; made on the host by tree_build.cpp fastbvh::widen): the planes of the child boxes as binary16, rounded
-// OUTWARD, one 32-bit word (min | max << 16) per child and axis, then the four child words: four 16-byte loads fetch a node.
+// Node format in HBM (DevFastNode, 128 B = one cache line, FOUR children; made on the host by tree_build.cpp fastbvh::widen): the planes of the child boxes as binary16,
+// rounded OUTWARD, one 32-bit word per child and axis, the four children's words of one axis side by side -- and each such 16-byte group TWICE: as (min | max << 16)
+// for rays that travel in the axis' positive direction and as (max | min << 16) for the others --, then the four child words. A ray loads, per axis, the group whose
+// low half is ITS near plane (three offsets it computes once), plus the child words: four 16-byte loads fetch what it needs of a node, 64 of the 128 bytes.
 // What binds the render kernels of scenes read from global memory (profiles/r04_measurements/ab_fast_node_formats.log): (1) the texture addresser -- ~21-27 of its
 // cycles per wave-level load instruction whatever the instruction's width, 99 % busy when a node step issues 4 loads for 2 boxes -- so what counts is the NUMBER of
-// load instructions per ray, not their bytes; (2) the dependent chain: a ray's node fetches follow one another, and the waves spend 54 % of their cycles waiting.
-// A 4-wide node of binary16 planes answers both: 4 loads bring 4 boxes (the 64-byte (min, max) node of rounds 2-3 brought 2), and a ray needs half as many round trips.
-// Per axis the ray swaps the halves of a plane word when it travels in the negative direction (one v_perm_b32 with a per-ray selector), so that the low half is the
-// near plane and the high half the far one; each plane then goes straight into t = fma ( plane, inv, -(o * inv) ) as the binary16 operand of v_fma_mix_f32: a box
-// costs three swaps, six fused multiply-adds, a v_max3, a v_min3 and the comparisons. Unlike the reference tree's test this one only has to be CONSERVATIVE (never
+// load instructions per ray, not their bytes; (2) the dependent chain: a ray's node fetches follow one another, and the waves spend 54 % of their cycles waiting;
+// (3) VALU issue. A 4-wide node of binary16 planes answers (1) and (2): 4 loads bring 4 boxes (the 64-byte (min, max) node of rounds 2-3 brought 2), and a ray needs
+// half as many round trips. Each plane goes straight into t = fma ( plane, inv, -(o * inv) ) as the binary16 operand of v_fma_mix_f32 (op_sel picks the half): a box
+// costs six fused multiply-adds, a v_max3, a v_min3 and the comparisons. (Until round 4's third session a node was 64 bytes with one (min | max << 16) word per child
+// and axis, and the ray swapped the halves with a v_perm_b32 per box and axis: twelve more VALU instructions per node step on a kernel bound by VALU issue; choosing
+// the group by ADDRESS costs three adds. Hall 198.9 -> 193.3 ms, sphere scene 302.2 -> 293.8: profiles/r04_measurements/ab_fast_tree_builder.log.) Unlike the
+// reference tree's test this one only has to be CONSERVATIVE (never
 // reject a box that holds a triangle the ray hits; DESIGN.md "Traversal policy"): rounding the planes outward only widens the box, and t carries two roundings
 // (o * inv, the fma) where the commit-time error budget (scene_host.cpp "numeric containment check") allows four. Planes are stored times DevScene::fast_scale (a
 // power of two: exact) so that every scene fits binary16's range; the ray's inverse direction is divided by it (exact too).
@@ -515,22 +519,20 @@ typedef _Float16 terra_half2 __attribute__ (( ext_vector_type ( 2 ) ));
 TD terra_half2 as_half2 ( uint32_t u ) { return __builtin_bit_cast ( terra_half2, u ); }
 // what a ray needs of itself for the fast tree's box test: the inverse direction -- clamped (a ray parallel to an axis has an infinite inverse direction there, and inf - inf
 // would drop that axis from the test: correct but ruinous, such a ray then visits every box along its line; clamped to +-2^100 the axis keeps its meaning: (plane - o) * 2^100
-// has the sign of "outside the slab") and divided by the planes' scale --, origin x clamped inverse direction, and per axis the byte selector that puts the near plane in the low half
+// has the sign of "outside the slab") and divided by the planes' scale --, origin x clamped inverse direction, and per axis the byte offset (inside a node) of the plane group that has the ray's near plane in the low half
 struct FastRay { V3 inv, oi; uint32_t px, py, pz; };
-#define TERRA_PERM_KEEP 0x03020100u
-#define TERRA_PERM_SWAP 0x01000302u
 TD FastRay fast_ray ( const Ray& ray, float inv_scale ) {
     FastRay f;
     const float cx = __builtin_fminf ( __builtin_fmaxf ( ray.inv.x, -0x1p100f ), 0x1p100f ), cy = __builtin_fminf ( __builtin_fmaxf ( ray.inv.y, -0x1p100f ), 0x1p100f ), cz = __builtin_fminf ( __builtin_fmaxf ( ray.inv.z, -0x1p100f ), 0x1p100f );
     f.oi = v3 ( ray.o.x * cx, ray.o.y * cy, ray.o.z * cz );
     f.inv = v3 ( cx * inv_scale, cy * inv_scale, cz * inv_scale );
-    f.px = cx < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP; f.py = cy < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP; f.pz = cz < 0.f ? TERRA_PERM_SWAP : TERRA_PERM_KEEP;
+    f.px = cx < 0.f ? 16u : 0u; f.py = cy < 0.f ? 48u : 32u; f.pz = cz < 0.f ? 80u : 64u;      // byte offsets of the ray's plane groups inside a node
     return f;
 }
-// entry distance of one child box from its three plane words (min | max << 16 per axis); hit = the ray's interval inside the box is not empty and starts no later
+// entry distance of one child box from its three plane words (near | far << 16 per axis: the ray loaded the group that has them this way round); hit = the ray's interval inside the box is not empty and starts no later
 // than the closest hit so far. `limit_up` = that hit's depth plus one ulp: t_enter <= depth is t_enter < limit_up, which folds into the min3 of the far planes.
 TD bool slab_half ( uint32_t wx, uint32_t wy, uint32_t wz, const FastRay& f, float limit_up, float& t_enter ) {
-    const terra_half2 x = as_half2 ( __builtin_amdgcn_perm ( wx, wx, f.px ) ), y = as_half2 ( __builtin_amdgcn_perm ( wy, wy, f.py ) ), z = as_half2 ( __builtin_amdgcn_perm ( wz, wz, f.pz ) );      // (near, far)
+    const terra_half2 x = as_half2 ( wx ), y = as_half2 ( wy ), z = as_half2 ( wz );      // (near, far): the ray loaded the group that has them this way round
     const float tnx = __builtin_fmaf ( ( float ) x.x, f.inv.x, -f.oi.x ), tfx = __builtin_fmaf ( ( float ) x.y, f.inv.x, -f.oi.x );
     const float tny = __builtin_fmaf ( ( float ) y.x, f.inv.y, -f.oi.y ), tfy = __builtin_fmaf ( ( float ) y.y, f.inv.y, -f.oi.y );
     const float tnz = __builtin_fmaf ( ( float ) z.x, f.inv.z, -f.oi.z ), tfz = __builtin_fmaf ( ( float ) z.y, f.inv.z, -f.oi.z );
@@ -643,19 +645,19 @@ TD void traverse_fast_resume ( const Tracer& T, const Ray& ray, const RayState& 
                 if ( ( int ) w < 0 ) w = fast_pop ( T, top );
                 uint32_t nw = w;                                     // (a leaf that waited on the stack stays in hand)
                 if ( ( int ) w >= 0 ) {
-                    const uint32_t off = w << 6;
-                    const uint4 q0 = *reinterpret_cast<const uint4*> ( nodes + off ), q1 = *reinterpret_cast<const uint4*> ( nodes + ( off + 16u ) ),
-                                q2 = *reinterpret_cast<const uint4*> ( nodes + ( off + 32u ) ), ch = *reinterpret_cast<const uint4*> ( nodes + ( off + 48u ) );      // {x0 y0 z0 x1} {y1 z1 x2 y2} {z2 x3 y3 z3} {children}
+                    const uint32_t off = w << 7;
+                    const uint4 gx = *reinterpret_cast<const uint4*> ( nodes + ( off + f.px ) ), gy = *reinterpret_cast<const uint4*> ( nodes + ( off + f.py ) ),
+                                gz = *reinterpret_cast<const uint4*> ( nodes + ( off + f.pz ) ), ch = *reinterpret_cast<const uint4*> ( nodes + ( off + 96u ) );      // {x0 x1 x2 x3} {y0 ..} {z0 ..} {children}
                     if ( COUNT ) ++c.nodes;
 #if TERRA_PHASE_STATS
                     c.ps[kPsTop64] += w < 64u; c.ps[kPsTop256] += w < 256u; c.ps[kPsTop1024] += w < 1024u; c.ps[kPsTop4096] += w < 4096u;
 #endif
                     const float limit_up = __uint_as_float ( __float_as_uint ( best.depth + 0.f ) + 1u );      // the next float up (FLT_MAX -> inf); + 0.f: a hit at depth -0 counts as +0
                     float te0, te1, te2, te3;
-                    const bool hit0 = slab_half ( q0.x, q0.y, q0.z, f, limit_up, te0 );
-                    const bool hit1 = slab_half ( q0.w, q1.x, q1.y, f, limit_up, te1 );
-                    const bool hit2 = slab_half ( q1.z, q1.w, q2.x, f, limit_up, te2 );
-                    const bool hit3 = slab_half ( q2.y, q2.z, q2.w, f, limit_up, te3 );
+                    const bool hit0 = slab_half ( gx.x, gy.x, gz.x, f, limit_up, te0 );
+                    const bool hit1 = slab_half ( gx.y, gy.y, gz.y, f, limit_up, te1 );
+                    const bool hit2 = slab_half ( gx.z, gy.z, gz.z, f, limit_up, te2 );
+                    const bool hit3 = slab_half ( gx.w, gy.w, gz.w, f, limit_up, te3 );
                     // nearest first: the entry distances (>= 0, so their bit patterns order like the floats) sorted with their child words; a box not entered sorts last
                     uint32_t k0 = hit0 ? __float_as_uint ( te0 ) : 0xffffffffu, k1 = hit1 ? __float_as_uint ( te1 ) : 0xffffffffu, k2 = hit2 ? __float_as_uint ( te2 ) : 0xffffffffu, k3 = hit3 ? __float_as_uint ( te3 ) : 0xffffffffu;
                     uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;

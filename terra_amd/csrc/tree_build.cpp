@@ -407,6 +407,8 @@ uint16_t half_outward ( double x, bool up ) {
 }
 
 // ---- the binary tree as 4-wide binary16 nodes -------------------------------------------------------------------------------------
+// child k's planes on axis a, for both ray directions (dev_types.h DevFastNode)
+static inline void set_planes ( DevFastNode& nd, int k, int a, uint32_t lo, uint32_t hi ) { nd.q[a][0][k] = lo | ( hi << 16 ); nd.q[a][1][k] = hi | ( lo << 16 ); }
 Wide widen ( const std::vector<DevNode>& n2, float scale ) {
     Wide out;
     struct Slot { float mn[3], mx[3]; uint32_t word; };
@@ -430,13 +432,13 @@ Wide widen ( const std::vector<DevNode>& n2, float scale ) {
             const DevNode& c = n2[slots[pick].word];
             slots[pick] = slot_of ( c, 0 ); slots[n++] = slot_of ( c, 1 );
         }
-        DevFastNode nd;
+        DevFastNode nd; memset ( &nd, 0, sizeof nd );
         for ( int k = 0; k < 4; ++k ) {
-            if ( k >= n ) { for ( int a = 0; a < 3; ++a ) nd.p[k][a] = 0x7bffu | ( 0xfbffu << 16 ); nd.child[k] = DEV_CHILD_EMPTY; continue; }      // an empty slot: min = +65504, max = -65504 -- no ray enters it
+            if ( k >= n ) { for ( int a = 0; a < 3; ++a ) set_planes ( nd, k, a, 0x7bffu, 0xfbffu ); nd.child[k] = DEV_CHILD_EMPTY; continue; }      // an empty slot: min = +65504, max = -65504 -- no ray enters it
             for ( int a = 0; a < 3; ++a ) {
                 const bool empty = ! ( slots[k].mn[a] <= slots[k].mx[a] );
                 const uint32_t lo = empty ? 0x7bffu : half_outward ( ( double ) slots[k].mn[a] * ( double ) scale, false ), hi = empty ? 0xfbffu : half_outward ( ( double ) slots[k].mx[a] * ( double ) scale, true );
-                nd.p[k][a] = lo | ( hi << 16 );
+                set_planes ( nd, k, a, lo, hi );
             }
             if ( inner ( slots[k].word ) ) { nd.child[k] = ( uint32_t ) src.size(); src.push_back ( slots[k].word ); out.nodes.push_back ( DevFastNode() ); kids.push_back ( 0 ); }
             else nd.child[k] = slots[k].word;
